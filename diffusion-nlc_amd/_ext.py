@@ -1,0 +1,142 @@
+"""ctypes binding of libnlc_hip.so (the C ABI declared in include/nlc_hip.h).
+
+The library is built in-tree by ``csrc/build.sh`` (hipcc --offload-arch=gfx950).  There is no
+CPU fallback: if the shared object is missing or a symbol is absent, importing the ops fails
+loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libnlc_hip.so"
+BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
+
+NLC_F32, NLC_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+OUT_NHWC, OUT_NCHW_F32 = 0, 1
+SCHED_VARIANTS = {
+    "ddim": 0, "ddim_simple": 1, "ddim_simple_orig": 2, "ddim_simple_drag": 3,
+    "ddpm": 4, "ddpm_orig": 5, "ddim_orig": 6,
+}
+CLIP_MODES = {"none": 0, "clamp": 1, "dynamic": 2}
+VAR_MODES = {"none": 0, "fixedsmall": 1, "fixedlarge": 2, "learned": 3}
+
+
+class NlcError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p),
+        ("C0", C.c_int32), ("C1", C.c_int32),
+        ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("upsample2x", C.c_int32),
+        ("w", C.c_void_p),
+        ("Cin_pad", C.c_int32), ("Cout_pad", C.c_int32),
+        ("bias", C.c_void_p),
+        ("emb", C.c_void_p),
+        ("emb_stride", C.c_int32),
+        ("res", C.c_void_p),
+        ("out_scale", C.c_float),
+        ("act", C.c_int32),
+        ("out", C.c_void_p),
+        ("out_mode", C.c_int32),
+    ]
+
+
+class SchedDesc(C.Structure):
+    _fields_ = [
+        ("xt", C.c_void_p), ("eps_out", C.c_void_p), ("noise", C.c_void_p),
+        ("known", C.c_void_p), ("mask", C.c_void_p),
+        ("sigma_t", C.c_void_p), ("sigma_prev", C.c_void_p),
+        ("eps_norm_sumsq", C.c_void_p),
+        ("dyn_s", C.c_void_p),
+        ("x0", C.c_void_p), ("x_prev", C.c_void_p), ("eps_used", C.c_void_p),
+        ("B", C.c_int32), ("C", C.c_int32), ("Cnet", C.c_int32), ("HW", C.c_int32),
+        ("variant", C.c_int32), ("clip", C.c_int32), ("var_mode", C.c_int32),
+        ("eta", C.c_float), ("min_var_coef", C.c_float),
+    ]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/nlc_hip.h declares
+SIGNATURES = {
+    "nlc_version": (C.c_int, []),
+    "nlc_last_error": (C.c_char_p, []),
+    "nlc_conv_pack_dims": (C.c_int, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
+    "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "nlc_groupnorm_workspace_bytes": (C.c_int64, [_i, _i, _i, _i]),
+    "nlc_groupnorm": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "nlc_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nlc_avgpool2x2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nlc_upsample2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nlc_pad_rb": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nlc_nhwc_to_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nlc_nchw_f32_to_nhwc": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nlc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "nlc_row_sumsq": (C.c_int, [_vp, _vp, _i, _i64, _i64, _vp]),
+    "nlc_refine_sigma": (C.c_int, [_vp, _f, _f, _f, _f, _f, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "nlc_sigma_correct": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "nlc_dynamic_threshold": (C.c_int, [_vp, _f, _f, _vp, _i, _i64, _vp]),
+    "nlc_sched_x0": (C.c_int, [C.POINTER(SchedDesc), _vp]),
+    "nlc_sched_step": (C.c_int, [C.POINTER(SchedDesc), _vp, _vp]),
+    "nlc_scale_rows": (C.c_int, [_vp, _vp, _f, _vp, _i, _i64, _vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 (works without a GPU)."""
+    if force:
+        for o in (_HERE / "csrc" / "obj").glob("*.o"):
+            o.unlink()
+    subprocess.run(["bash", str(BUILD_SCRIPT)], check=True)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libnlc_hip.so and bind every declared symbol.  Raises NlcError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NlcError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            f"Build it with `bash {BUILD_SCRIPT}` or `python -c 'import __graft_entry__ as g; g.build()'`."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise NlcError(f"libnlc_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.nlc_version()
+    if ver != 1:
+        raise NlcError(f"libnlc_hip.so ABI version {ver} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().nlc_last_error().decode("utf-8", "replace")
+        raise NlcError(f"{what} failed (rc={rc}): {msg}")
+
+
+def pack_dims(dtype: int):
+    a, b = C.c_int(), C.c_int()
+    check(load().nlc_conv_pack_dims(dtype, C.byref(a), C.byref(b)), "nlc_conv_pack_dims")
+    return a.value, b.value

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libnlc_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+out="$here/../libnlc_hip.so"
+mkdir -p "$here/obj"
+pids=()
+for f in abi conv_igemm groupnorm attention elementwise sampler; do
+  if [ ! -f "$here/obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/obj/$f.o" ] || [ "$here/common.h" -nt "$here/obj/$f.o" ] || [ "$root/include/nlc_hip.h" -nt "$here/obj/$f.o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$root/include" -I"$here" -c "$here/$f.hip" -o "$here/obj/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" "$here"/obj/*.o
+echo "built $out"

@@ -1,0 +1,108 @@
+// Shared device/host helpers for libnlc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "nlc_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef unsigned short bf16_raw;   // storage type for bf16 in memory
+
+#define NLC_WAVE 64
+
+void nlc_set_error(const char* fmt, ...);
+
+#define NLC_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            nlc_set_error(__VA_ARGS__);                          \
+            return NLC_EINVAL;                                   \
+        }                                                        \
+    } while (0)
+
+#define NLC_CHECK_LAUNCH(name)                                                    \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            nlc_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return NLC_ELAUNCH;                                                   \
+        }                                                                         \
+    } while (0)
+
+// ---- scalar conversions -------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) {
+    return __uint_as_float(((unsigned)v) << 16);
+}
+// round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 and keeps NaN a NaN
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_raw, b);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int kPerChunk = 4;            // elements per 16-byte chunk
+    static constexpr int kDtype = NLC_F32;
+    __device__ static float load(const float* p) { return *p; }
+    __device__ static void store(float* p, float v) { *p = v; }
+};
+template <> struct ElemTraits<bf16_raw> {
+    static constexpr int kPerChunk = 8;
+    static constexpr int kDtype = NLC_BF16;
+    __device__ static float load(const bf16_raw* p) { return bf16_to_f32(*p); }
+    __device__ static void store(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// unpack a 16-byte chunk to floats / pack floats into a chunk
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const uint4& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const uint4& c, float* f) {
+    f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y);
+    f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_raw>(const uint4& c, float* f) {
+    f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+    f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+    f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+    f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 f32_to_chunk(const float* f);
+template <> __device__ __forceinline__ uint4 f32_to_chunk<float>(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                      __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 f32_to_chunk<bf16_raw>(const float* f) {
+    uint4 c;
+    c.x = (unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16);
+    c.y = (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16);
+    c.z = (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16);
+    c.w = (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16);
+    return c;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == NLC_ACT_SILU) return silu_exact(v);
+    if (act == NLC_ACT_GELU) return gelu_erf(v);
+    return v;
+}
+
+// wave-wide reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

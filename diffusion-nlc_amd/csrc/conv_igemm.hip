@@ -1,0 +1,296 @@
+// Implicit-GEMM convolution / linear on MFMA for gfx950.
+//
+//   out[m][n] = act( (sum_{tap,c} in[pixel(m)+tap][c] * w[n][tap][c] + bias[n] + emb[b(m)][n]
+//                     + res[m][n]) * out_scale )
+//
+// M = B*Hout*Wout output pixels (rows), N = Cout, K = KH*KW*Cin.  Activations are NHWC so
+// the K dimension (channels of one tap) is contiguous for both operands; no im2col buffer
+// is ever formed: the A tile rows are gathered straight from the input image, zero-filled
+// outside the image (padding), optionally through a virtual nearest 2x upsample and across
+// the channel-concatenation of two tensors.
+//
+// Tile: 128 (pixels) x 128 (cout) per 256-thread workgroup, 4 waves as 2x2, each wave
+// 64x64 = 4x4 MFMA tiles of 16x16.  K advances 128 bytes per row per step (64 bf16 / 32 f32),
+// double-buffered in LDS (64 KiB -> 2 workgroups per CU), global->register->LDS staging with
+// the next step's loads in flight under the current step's MFMAs.  LDS rows are 128 B with
+// the 16-byte chunk index XOR-swizzled by (row>>1)&7 so every ds_read_b128 lane group hits
+// 16 distinct 16-byte slots (conflict-free).
+//
+//   bf16: v_mfma_f32_16x16x32_bf16, f32 accumulate.
+//   f32 : v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) - 4 MFMAs per 16-byte fragment pair,
+//         with the same k permutation on both operands.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int KB_BYTES = 128;
+constexpr int NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM + BN) * KB_BYTES;   // 32 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;          // 64 KiB
+
+struct KParams {
+    const char* x0; const char* x1;
+    int C0, C1, Ctot;
+    int B, Hin, Win, Hout, Wout, Cout;
+    int KH, KW, stride, pad_t, pad_l, ups;
+    const char* w; int Cin_pad, Cout_pad;
+    const float* bias; const float* emb; int emb_stride;
+    const char* res; float out_scale; int act;
+    char* out; int out_mode;
+    int M, MT, NT;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_raw> {
+    static constexpr int KBE = KB_BYTES / 2;   // 64 elements per k-block
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KBE = KB_BYTES / 4;   // 32 elements per k-block
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * KB_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PER = ElemTraits<T>::kPerChunk;
+    constexpr int KBE = Mma<T>::KBE;
+    constexpr int ES = (int)sizeof(T);
+
+    // ---- XCD-aware block -> tile mapping: blocks b and b+8 share an XCD (own L2); give each
+    //      XCD a contiguous run of tiles so the input rows its tiles share stay in that L2.
+    const int nblk = p.MT * p.NT;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lc = tid & 7;        // 16-byte chunk within the 128-byte k-block row
+    const int lr = tid >> 3;       // 0..31, rows lr + 32*i
+
+    const int HWo = p.Hout * p.Wout;
+    const int HL = p.ups ? 2 * p.Hin : p.Hin;
+    const int WL = p.ups ? 2 * p.Win : p.Win;
+    const int ntaps = p.KH * p.KW;
+    const int ncb = p.Cin_pad / KBE;
+    const int nk = ntaps * ncb;
+
+    // ---- per-thread gather rows (4 A rows, 4 B rows)
+    int64_t a_img[4]; int a_iy0[4], a_ix0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lr + 32 * i;
+        if (m < p.M) {
+            const int b = m / HWo; const int rem = m - b * HWo;
+            const int oy = rem / p.Wout; const int ox = rem - oy * p.Wout;
+            a_img[i] = (int64_t)b * p.Hin * p.Win;
+            a_iy0[i] = oy * p.stride - p.pad_t;
+            a_ix0[i] = ox * p.stride - p.pad_l;
+        } else {
+            a_img[i] = 0; a_iy0[i] = -(1 << 28); a_ix0[i] = -(1 << 28);
+        }
+    }
+    const int64_t wrow = (int64_t)ntaps * p.Cin_pad * ES;
+    const char* b_row0 = p.w + (int64_t)(n0 + lr) * wrow + lc * PER * ES;
+    const char* b_row1 = b_row0 + 32 * wrow;
+    const char* b_row2 = b_row0 + 64 * wrow;
+    const char* b_row3 = b_row0 + 96 * wrow;
+
+    // staging registers are named scalars (not arrays): keeps them out of scratch
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define NLC_LOAD_A(i, dst)                                                                              \
+    {                                                                                                   \
+        int iy = a_iy0[i] + r, ix = a_ix0[i] + s;                                                       \
+        const bool ok = cvalid && iy >= 0 && iy < HL && ix >= 0 && ix < WL;                             \
+        if (p.ups) { iy >>= 1; ix >>= 1; }                                                              \
+        const char* ptr = ok ? src + ((a_img[i] + (int64_t)iy * p.Win + ix) * C + ch) * ES : p.x0;      \
+        uint4 v = *reinterpret_cast<const uint4*>(ptr);                                                 \
+        v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;             \
+        dst = v;                                                                                        \
+    }
+#define NLC_LOAD_REGS(kt_)                                                                              \
+    {                                                                                                   \
+        const int tap = (kt_) / ncb, cb = (kt_) - tap * ncb;                                            \
+        const int r = tap / p.KW, s = tap - r * p.KW;                                                   \
+        const int cch = cb * KBE + lc * PER; /* logical (concatenated) channel */                       \
+        const char* src; int C, ch;                                                                     \
+        if (cch < p.C0) { src = p.x0; C = p.C0; ch = cch; }                                             \
+        else { src = p.x1; C = p.C1; ch = cch - p.C0; }                                                 \
+        const bool cvalid = cch < p.Ctot;                                                               \
+        if (!cvalid) { src = p.x0; C = p.C0; ch = 0; }                                                  \
+        NLC_LOAD_A(0, ra0) NLC_LOAD_A(1, ra1) NLC_LOAD_A(2, ra2) NLC_LOAD_A(3, ra3)                     \
+        const int64_t boff = ((int64_t)tap * p.Cin_pad + cb * KBE) * ES;                                \
+        rb0 = *reinterpret_cast<const uint4*>(b_row0 + boff);                                           \
+        rb1 = *reinterpret_cast<const uint4*>(b_row1 + boff);                                           \
+        rb2 = *reinterpret_cast<const uint4*>(b_row2 + boff);                                           \
+        rb3 = *reinterpret_cast<const uint4*>(b_row3 + boff);                                           \
+    }
+#define NLC_STORE_REGS(stage_)                                                                          \
+    {                                                                                                   \
+        char* As_ = smem + (stage_) * STAGE_BYTES;                                                      \
+        char* Bs_ = As_ + BM * KB_BYTES;                                                                \
+        *reinterpret_cast<uint4*>(As_ + lds_off(lr, lc)) = ra0;                                         \
+        *reinterpret_cast<uint4*>(As_ + lds_off(lr + 32, lc)) = ra1;                                    \
+        *reinterpret_cast<uint4*>(As_ + lds_off(lr + 64, lc)) = ra2;                                    \
+        *reinterpret_cast<uint4*>(As_ + lds_off(lr + 96, lc)) = ra3;                                    \
+        *reinterpret_cast<uint4*>(Bs_ + lds_off(lr, lc)) = rb0;                                         \
+        *reinterpret_cast<uint4*>(Bs_ + lds_off(lr + 32, lc)) = rb1;                                    \
+        *reinterpret_cast<uint4*>(Bs_ + lds_off(lr + 64, lc)) = rb2;                                    \
+        *reinterpret_cast<uint4*>(Bs_ + lds_off(lr + 96, lc)) = rb3;                                    \
+    }
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int stage) {
+        const char* As = smem + stage * STAGE_BYTES;
+        const char* Bs = As + BM * KB_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[4], fb[4];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, chunk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, chunk));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    NLC_LOAD_REGS(0)
+    NLC_STORE_REGS(0)
+    __syncthreads();
+    // steady state: next step's global loads are in flight under this step's MFMAs; the last
+    // step is peeled so the loop body has no conditional around the loads.
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        NLC_LOAD_REGS(kt + 1)
+        compute(kt & 1);
+        NLC_STORE_REGS((kt & 1) ^ 1)
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    // ---- epilogue: C[row = i*16 + fq*4 + reg][col = j*16 + fr]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int m = m0 + wm * 64 + i * 16 + fq * 4 + reg;
+            if (m >= p.M) continue;
+            const int b = m / HWo;
+            const int rem = m - b * HWo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fr;
+                if (n >= p.Cout) continue;
+                float v = acc[i][j][reg];
+                if (p.bias) v += p.bias[n];
+                if (p.emb) v += p.emb[(int64_t)b * p.emb_stride + n];
+                if (p.res) v += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n);
+                v *= p.out_scale;
+                v = apply_act(v, p.act);
+                if (p.out_mode == NLC_OUT_NHWC)
+                    ElemTraits<T>::store(reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n, v);
+                else
+                    reinterpret_cast<float*>(p.out)[((int64_t)b * p.Cout + n) * HWo + rem] = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch(const KParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_igemm_kernel<T>, dim3(p.MT * p.NT), dim3(NTHREADS), LDS_BYTES, stream, p);
+    NLC_CHECK_LAUNCH("nlc_conv2d");
+    return NLC_OK;
+}
+
+}  // namespace
+
+extern "C" int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult) {
+    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv_pack_dims: bad dtype %d", dtype);
+    if (cout_mult) *cout_mult = BN;
+    if (cin_mult) *cin_mult = dtype == NLC_BF16 ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
+    return NLC_OK;
+}
+
+extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
+    NLC_REQUIRE(d != nullptr, "nlc_conv2d: null descriptor");
+    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv2d: bad dtype %d", dtype);
+    const int per = dtype == NLC_BF16 ? 8 : 4;
+    const int kbe = dtype == NLC_BF16 ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
+    NLC_REQUIRE(d->x0 && d->w && d->out, "nlc_conv2d: null tensor pointer");
+    NLC_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0,
+                "nlc_conv2d: non-positive dims");
+    NLC_REQUIRE(d->C0 > 0 && d->C0 % per == 0, "nlc_conv2d: C0=%d must be a positive multiple of %d", d->C0, per);
+    NLC_REQUIRE(d->C1 >= 0 && d->C1 % per == 0 && ((d->C1 == 0) == (d->x1 == nullptr)),
+                "nlc_conv2d: C1=%d / x1 mismatch (multiple of %d required)", d->C1, per);
+    NLC_REQUIRE(d->Cin_pad % kbe == 0 && d->Cin_pad >= d->C0 + d->C1 && d->Cin_pad - (d->C0 + d->C1) < kbe,
+                "nlc_conv2d: Cin_pad=%d must be C0+C1=%d rounded up to %d", d->Cin_pad, d->C0 + d->C1, kbe);
+    NLC_REQUIRE(d->Cout_pad % BN == 0 && d->Cout_pad >= d->Cout, "nlc_conv2d: Cout_pad=%d must be a multiple of %d >= Cout=%d",
+                d->Cout_pad, BN, d->Cout);
+    NLC_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH <= 7 && d->KW <= 7 && d->stride >= 1, "nlc_conv2d: bad kernel/stride");
+    NLC_REQUIRE(d->pad_t >= 0 && d->pad_l >= 0, "nlc_conv2d: negative padding");
+    {   // every output pixel's top-left tap must start inside [-(pad), HL): the far side is zero-filled
+        const int HL = d->upsample2x ? 2 * d->Hin : d->Hin, WL = d->upsample2x ? 2 * d->Win : d->Win;
+        NLC_REQUIRE((d->Hout - 1) * d->stride - d->pad_t < HL && (d->Wout - 1) * d->stride - d->pad_l < WL,
+                    "nlc_conv2d: output %dx%d does not fit input %dx%d (stride %d pad %d,%d)", d->Hout, d->Wout, HL, WL,
+                    d->stride, d->pad_t, d->pad_l);
+    }
+    NLC_REQUIRE(d->act >= NLC_ACT_NONE && d->act <= NLC_ACT_GELU, "nlc_conv2d: bad act %d", d->act);
+    NLC_REQUIRE(d->out_mode == NLC_OUT_NHWC || d->out_mode == NLC_OUT_NCHW_F32, "nlc_conv2d: bad out_mode");
+    NLC_REQUIRE(!(d->emb) || d->emb_stride >= d->Cout, "nlc_conv2d: emb_stride < Cout");
+    const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
+    NLC_REQUIRE(M64 < (1ll << 31) - BM, "nlc_conv2d: too many output pixels");
+
+    KParams p;
+    p.x0 = (const char*)d->x0; p.x1 = (const char*)d->x1;
+    p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
+    p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.ups = d->upsample2x ? 1 : 0;
+    p.w = (const char*)d->w; p.Cin_pad = d->Cin_pad; p.Cout_pad = d->Cout_pad;
+    p.bias = d->bias; p.emb = d->emb; p.emb_stride = d->emb_stride;
+    p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act;
+    p.out = (char*)d->out; p.out_mode = d->out_mode;
+    p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
+    if (dtype == NLC_BF16) return launch<bf16_raw>(p, (hipStream_t)stream);
+    return launch<float>(p, (hipStream_t)stream);
+}

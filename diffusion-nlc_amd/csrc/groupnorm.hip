@@ -1,0 +1,221 @@
+// GroupNorm (+FiLM scale/shift) (+SiLU) on channels-last activations, gfx950.
+//
+// HBM-bound: 2 reads + 1 write of the activation.  Two launches:
+//   1. gn_stats:  grid (NBLK, B).  Each workgroup streams a contiguous pixel range of one
+//      image with fully coalesced 16-byte loads (a pixel's channels are contiguous), keeps
+//      per-thread f32 sum / sum-of-squares for a FIXED set of channels, reduces them in LDS in
+//      a fixed order (deterministic - no atomics) to per-group partials -> workspace.
+//   2. gn_apply:  grid (NBLK2, B).  Each workgroup folds the partials (f64) into
+//      a[c] = rstd*gamma*(1+scale), b[c] = (beta-mean*rstd*gamma)*(1+scale)+shift  in LDS, then
+//      streams  y = act(a[c]*x + b[c])  with 16-byte loads/stores.
+// The input may be the channel concatenation of two tensors (UNet skip connections), so the
+// torch.cat of the reference (src/unet_adm.py:662) is never materialised.
+// y = a*x + b is the same factorisation ATen's CPU group_norm kernel uses.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAX_SLOTS = 4;       // chunk slots per thread per pixel (C <= 256*4*PER)
+constexpr int MAX_NBLK = 64;
+
+struct GNParams {
+    const char* x0; const char* x1;
+    int C0, C1, C, B, HW, G, gs;
+    int nch;            // 16-byte chunks per pixel
+    int nslot;          // chunk slots per thread
+    int tpp;            // threads per pixel (= min(nch, 256))
+    int ps;             // pixels processed concurrently per block
+    int nblk;           // stats blocks per image
+    int pix_per_blk;
+    float eps;
+    const float* gamma; const float* beta;
+    const float* scale; const float* shift; int ss_stride;
+    int silu;
+    char* out;
+    float* ws;          // [B][nblk][G][2]
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 load_chunk(const GNParams& p, int b, int64_t pix, int chunk) {
+    constexpr int PER = ElemTraits<T>::kPerChunk;
+    const int c = chunk * PER;
+    const char* ptr;
+    if (c < p.C0) ptr = p.x0 + (((int64_t)b * p.HW + pix) * p.C0 + c) * (int)sizeof(T);
+    else ptr = p.x1 + (((int64_t)b * p.HW + pix) * p.C1 + (c - p.C0)) * (int)sizeof(T);
+    return *reinterpret_cast<const uint4*>(ptr);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const GNParams p) {
+    constexpr int PER = ElemTraits<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);   // [ps][C][2]
+
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const int active = p.tpp * p.ps;
+    const int tx = tid % p.tpp, pl = tid / p.tpp;
+    const int pix0 = blk * p.pix_per_blk;
+    const int pix1 = min(pix0 + p.pix_per_blk, p.HW);
+
+    float s[MAX_SLOTS][PER], q[MAX_SLOTS][PER];
+#pragma unroll
+    for (int k = 0; k < MAX_SLOTS; ++k)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { s[k][j] = 0.f; q[k][j] = 0.f; }
+
+    if (tid < active) {
+        for (int pix = pix0 + pl; pix < pix1; pix += p.ps) {
+#pragma unroll
+            for (int k = 0; k < MAX_SLOTS; ++k) {
+                const int chunk = tx + k * p.tpp;
+                if (k < p.nslot && chunk < p.nch) {
+                    float f[PER];
+                    chunk_to_f32<T>(load_chunk<T>(p, b, pix, chunk), f);
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) { s[k][j] += f[j]; q[k][j] += f[j] * f[j]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAX_SLOTS; ++k) {
+            const int chunk = tx + k * p.tpp;
+            if (k < p.nslot && chunk < p.nch) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int c = chunk * PER + j;
+                    red[((int64_t)pl * p.C + c) * 2 + 0] = s[k][j];
+                    red[((int64_t)pl * p.C + c) * 2 + 1] = q[k][j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = tid; g < p.G; g += NT) {
+        float ss = 0.f, qq = 0.f;
+        for (int l = 0; l < p.ps; ++l)
+            for (int c = g * p.gs; c < (g + 1) * p.gs; ++c) {
+                ss += red[((int64_t)l * p.C + c) * 2 + 0];
+                qq += red[((int64_t)l * p.C + c) * 2 + 1];
+            }
+        float* w = p.ws + (((int64_t)b * p.nblk + blk) * p.G + g) * 2;
+        w[0] = ss; w[1] = qq;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const GNParams p) {
+    constexpr int PER = ElemTraits<T>::kPerChunk;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ca = reinterpret_cast<float*>(smem);   // [C]
+    float* cb = ca + p.C;                          // [C]
+    float* gm = cb + p.C;                          // [G] mean
+    float* gr = gm + p.G;                          // [G] rstd
+
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int g = tid; g < p.G; g += NT) {
+        double ss = 0.0, qq = 0.0;
+        const float* w = p.ws + ((int64_t)b * p.nblk * p.G + g) * 2;
+        for (int k = 0; k < p.nblk; ++k) { ss += (double)w[(int64_t)k * p.G * 2]; qq += (double)w[(int64_t)k * p.G * 2 + 1]; }
+        const double n = (double)p.HW * p.gs;
+        const double mean = ss / n;
+        double var = qq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gm[g] = (float)mean;
+        gr[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += NT) {
+        const int g = c / p.gs;
+        float a = gr[g] * (p.gamma ? p.gamma[c] : 1.f);
+        float bb = (p.beta ? p.beta[c] : 0.f) - gm[g] * a;
+        if (p.scale) {
+            const float sc = 1.f + p.scale[(int64_t)b * p.ss_stride + c];
+            const float sh = p.shift[(int64_t)b * p.ss_stride + c];
+            a *= sc; bb = bb * sc + sh;
+        }
+        ca[c] = a; cb[c] = bb;
+    }
+    __syncthreads();
+
+    const int64_t total = (int64_t)p.HW * p.nch;      // chunks in this image
+    T* outb = reinterpret_cast<T*>(p.out) + (int64_t)b * p.HW * p.C;
+    for (int64_t e = (int64_t)blockIdx.x * NT + tid; e < total; e += (int64_t)gridDim.x * NT) {
+        const int64_t pix = e / p.nch;
+        const int chunk = (int)(e - pix * p.nch);
+        float f[PER];
+        chunk_to_f32<T>(load_chunk<T>(p, b, pix, chunk), f);
+        const int c0 = chunk * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            float y = ca[c0 + j] * f[j] + cb[c0 + j];
+            if (p.silu) y = (sizeof(T) == 4) ? silu_exact(y) : silu_f(y);
+            f[j] = y;
+        }
+        *reinterpret_cast<uint4*>(outb + pix * p.C + c0) = f32_to_chunk<T>(f);
+    }
+}
+
+int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, int dtype) {
+    const int per = dtype == NLC_BF16 ? 8 : 4, es = dtype == NLC_BF16 ? 2 : 4;
+    p.x0 = (const char*)x0; p.x1 = (const char*)x1;
+    p.C0 = C0; p.C1 = C1; p.C = C0 + C1; p.B = B; p.HW = HW; p.G = groups; p.gs = p.C / groups;
+    p.nch = p.C / per;
+    p.tpp = p.nch < NT ? p.nch : NT;
+    p.nslot = cdiv(p.nch, p.tpp);
+    p.ps = NT / p.tpp; if (p.ps < 1) p.ps = 1;
+    int64_t bytes = (int64_t)HW * p.C * es;
+    int nblk = cdiv(bytes, 65536);
+    if (nblk < 1) nblk = 1;
+    if (nblk > MAX_NBLK) nblk = MAX_NBLK;
+    if (nblk > HW) nblk = HW;
+    p.pix_per_blk = cdiv(HW, nblk);
+    p.nblk = cdiv(HW, p.pix_per_blk);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t nlc_groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
+    (void)HW; (void)C;
+    return (int64_t)B * MAX_NBLK * groups * 2 * sizeof(float);
+}
+
+extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, float eps,
+                             const float* gamma, const float* beta, const float* scale, const float* shift,
+                             int ss_stride, int silu, void* out, void* workspace, int dtype, void* stream) {
+    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_groupnorm: bad dtype %d", dtype);
+    const int per = dtype == NLC_BF16 ? 8 : 4;
+    NLC_REQUIRE(x0 && out && workspace, "nlc_groupnorm: null pointer");
+    NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm: bad dims");
+    NLC_REQUIRE(C0 % per == 0 && C1 % per == 0, "nlc_groupnorm: C0=%d, C1=%d must be multiples of %d", C0, C1, per);
+    NLC_REQUIRE((C1 == 0) == (x1 == nullptr), "nlc_groupnorm: x1/C1 mismatch");
+    const int C = C0 + C1;
+    NLC_REQUIRE(C % groups == 0, "nlc_groupnorm: C=%d not divisible by groups=%d", C, groups);
+    NLC_REQUIRE(C / per <= NT * MAX_SLOTS, "nlc_groupnorm: C=%d too large", C);
+    NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm: scale/shift must come together");
+    NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm: ss_stride < C");
+    GNParams p;
+    fill_params(p, x0, x1, C0, C1, B, HW, groups, dtype);
+    p.eps = eps; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
+    p.silu = silu; p.out = (char*)out; p.ws = (float*)workspace;
+    const size_t lds_stats = (size_t)p.ps * p.C * 2 * sizeof(float);
+    const size_t lds_apply = ((size_t)2 * p.C + 2 * p.G) * sizeof(float);
+    NLC_REQUIRE(lds_stats <= 64 * 1024 && lds_apply <= 64 * 1024, "nlc_groupnorm: LDS budget exceeded (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int es = dtype == NLC_BF16 ? 2 : 4;
+    int64_t chunks = (int64_t)HW * p.nch;
+    int nblk2 = cdiv(chunks, NT * 8);
+    if (nblk2 < 1) nblk2 = 1;
+    if (nblk2 > 2048 / B + 1) nblk2 = 2048 / B + 1;
+    (void)es;
+    if (dtype == NLC_BF16) {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_raw>, dim3(nblk2, B), dim3(NT), lds_apply, st, p);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk2, B), dim3(NT), lds_apply, st, p);
+    }
+    NLC_CHECK_LAUNCH("nlc_groupnorm");
+    return NLC_OK;
+}

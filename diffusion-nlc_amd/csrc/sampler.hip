@@ -1,0 +1,391 @@
+// Sampler-state kernels: everything the DDIM/EDM + NLC loop does to the f32 NCHW state
+// between two network evaluations.  All HBM-bound and per-sample; the per-sample scalars
+// (sigma_t, sigma_prev, t, c_in) live in small device arrays so the loop has no host syncs.
+// Formulas restate src/experiments.py:186-207,273-293,360-370,401-431,457-459 and
+// src/schedulers.py:185-190,367-390,407-449 (+ the variants at :465-627), operation by operation
+// in f32 so results track the CPU reference to rounding.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int RT = 1024;   // threads for one-block-per-sample reductions
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) { for (int i = 0; i < nw; ++i) r += sh[i]; sh[0] = r; }
+    __syncthreads();
+    r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// sumsq[b] = sum_{d<D} x[b*row_stride + d]^2, one workgroup per sample, fixed summation order.
+__global__ __launch_bounds__(RT) void row_sumsq_kernel(const float* __restrict__ x, float* __restrict__ sumsq,
+                                                      int64_t row_stride, int64_t D) {
+    __shared__ float sh[RT / 64];
+    const float* row = x + (int64_t)blockIdx.x * row_stride;
+    float acc = 0.f;
+    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    int64_t i0 = 0;
+    if (vec) {
+        const int64_t n4 = D >> 2;
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        for (int64_t i = threadIdx.x; i < n4; i += RT) {
+            const float4 v = r4[i];
+            acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+        }
+        i0 = n4 << 2;
+    }
+    for (int64_t i = i0 + threadIdx.x; i < D; i += RT) acc += row[i] * row[i];
+    const float tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) sumsq[blockIdx.x] = tot;
+}
+
+// first index i with table[i] >= v  (torch.searchsorted, right=False), n if none
+__device__ __forceinline__ int lower_bound(const float* __restrict__ table, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (table[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(RT) void refine_sigma_kernel(const float* __restrict__ sumsq, float sqrt_dim, float norm_max,
+                                                          float norm_min, float sigma_sched, float sigma_prev_sched,
+                                                          int refine, const float* __restrict__ sigmas, int n_sigmas,
+                                                          int t_sched, int time_shift, float* __restrict__ sigma_t,
+                                                          float* __restrict__ sigma_prev, float* __restrict__ t,
+                                                          float* __restrict__ c_in, int B) {
+    __shared__ int s_min;
+    if (threadIdx.x == 0) s_min = 0x7fffffff;
+    __syncthreads();
+    // pass 1: sigma and integer t per sample, batch minimum of t (src/experiments.py:411)
+    for (int b = threadIdx.x; b < B; b += RT) {
+        float sg = sigma_sched; int ti = t_sched;
+        if (refine) {
+            const float norm_x = sqrtf(sumsq[b]) / sqrt_dim;
+            const float min_dist = fmaxf(norm_x - norm_max, 0.f);
+            const float max_dist = norm_x + norm_min;
+            sg = fminf(fmaxf(sigma_sched, min_dist), max_dist);
+            ti = lower_bound(sigmas, n_sigmas, sg);
+            atomicMin(&s_min, ti);
+        }
+        sigma_t[b] = sg;
+        sigma_prev[b] = sigma_prev_sched;
+        t[b] = (float)ti;   // provisional
+    }
+    __syncthreads();
+    const int shift = (refine && s_min > 0) ? time_shift : 0;
+    for (int b = threadIdx.x; b < B; b += RT) {
+        float tf = t[b] - (float)shift;
+        tf = fminf(fmaxf(tf, 0.f), 1000.f);
+        t[b] = tf;
+        const float sg = sigma_t[b];
+        c_in[b] = sqrtf(1.0f / (sg * sg + 1.0f));
+    }
+}
+
+__global__ void sigma_correct_kernel(const float* __restrict__ r, int partial, const float* __restrict__ sigmas, int n_sigmas,
+                                     float* __restrict__ sigma_t, float* __restrict__ sigma_prev, float* __restrict__ t,
+                                     float* __restrict__ c_in, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float st = sigma_t[b], sp = sigma_prev[b];
+    const float dist_hat = st * (1.0f + r[b]);
+    const float dist_prev_hat = dist_hat * (sp / st);
+    float tf = (float)lower_bound(sigmas, n_sigmas, dist_hat);
+    tf = fminf(fmaxf(tf, 0.f), 1000.f);
+    sigma_t[b] = dist_hat;
+    if (!partial) sigma_prev[b] = dist_prev_hat;
+    t[b] = tf;
+    c_in[b] = sqrtf(1.0f / (dist_hat * dist_hat + 1.0f));
+}
+
+// ---- exact per-sample quantile of |x| (torch.quantile, linear interpolation) by radix select.
+//      One workgroup per sample; 4 passes over 8-bit digits of the (non-negative) float bit pattern.
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+__global__ __launch_bounds__(RT) void quantile_kernel(const float* __restrict__ x, float q, float max_value,
+                                                     float* __restrict__ s_out, int64_t D) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_k, s_cnt_le, s_next;
+    const float* row = x + (int64_t)blockIdx.x * D;
+    // rank arithmetic in f32 exactly as ATen does: rank = q * (n-1)
+    const float rank = q * (float)(D - 1);
+    const float rank_lo = floorf(rank);
+    const float w = rank - rank_lo;
+    unsigned k = (unsigned)rank_lo;            // 0-based order statistic
+    unsigned prefix = 0, mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = threadIdx.x; i < 256; i += RT) hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < D; i += RT) {
+            const unsigned u = abs_bits(row[i]);
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned acc = 0; int bin = 0;
+            for (; bin < 256; ++bin) {
+                if (acc + hist[bin] > k) break;
+                acc += hist[bin];
+            }
+            s_k = k - acc;
+            s_prefix = prefix | ((unsigned)bin << shift);
+        }
+        __syncthreads();
+        k = s_k; prefix = s_prefix; mask |= (255u << shift);
+        __syncthreads();
+    }
+    // prefix is now the bit pattern of sorted[lo]; find sorted[lo+1]
+    if (threadIdx.x == 0) { s_cnt_le = 0; s_next = 0x7fffffffu; }
+    __syncthreads();
+    unsigned cnt = 0, nxt = 0x7fffffffu;
+    for (int64_t i = threadIdx.x; i < D; i += RT) {
+        const unsigned u = abs_bits(row[i]);
+        if (u <= prefix) ++cnt; else nxt = min(nxt, u);
+    }
+    atomicAdd(&s_cnt_le, cnt);
+    atomicMin(&s_next, nxt);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v_lo = __uint_as_float(prefix);
+        const unsigned lo_idx = (unsigned)rank_lo;
+        float v_hi = v_lo;
+        if (ceilf(rank) > rank_lo && s_cnt_le <= lo_idx + 1) v_hi = __uint_as_float(s_next);
+        // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+        const float diff = v_hi - v_lo;
+        float s = (w < 0.5f) ? (v_lo + w * diff) : (v_hi - diff * (1.0f - w));
+        s = fminf(fmaxf(s, 1.0f), max_value);
+        s_out[blockIdx.x] = s;
+    }
+}
+
+// ---- fused scheduler update ---------------------------------------------------------------
+struct SchedScalars {
+    float st, sp, eps_mul, eps_div, min_lv, max_lv, abp;
+    bool norm;
+};
+__device__ __forceinline__ SchedScalars sched_scalars(const nlc_sched_desc& d, int b) {
+    SchedScalars s;
+    s.st = d.sigma_t[b]; s.sp = d.sigma_prev[b];
+    s.norm = d.eps_norm_sumsq != nullptr;
+    s.eps_mul = sqrtf((float)((int64_t)d.C * d.HW));
+    s.eps_div = s.norm ? fmaxf(sqrtf(d.eps_norm_sumsq[b]), 1e-12f) : 1.f;
+    // get_eps_logvar, src/schedulers.py:367-380
+    const float st2 = s.st * s.st, sp2 = s.sp * s.sp;
+    float beta_t = fabsf((st2 - sp2) / (st2 + 1.0f));
+    beta_t = fmaxf(beta_t, 1e-20f);
+    const float alpha_t = 1.0f / (st2 + 1.0f);
+    const float alpha_prev = 1.0f / (sp2 + 1.0f);
+    float coef = (1.0f - alpha_prev) / (1.0f - alpha_t);
+    coef = fminf(fmaxf(coef, 0.f), 1.f);
+    const float post_var = beta_t * coef;
+    s.max_lv = logf(beta_t);
+    s.min_lv = logf(fmaxf(post_var, d.min_var_coef));
+    s.abp = alpha_prev;
+    return s;
+}
+__device__ __forceinline__ float sched_eps(const nlc_sched_desc& d, const SchedScalars& s, int b, int c, int p) {
+    float e = d.eps_out[((int64_t)b * d.Cnet + c) * d.HW + p];
+    if (s.norm) e = (s.eps_mul * e) / s.eps_div;      // utils.normalize: sqrt(D)*x/denom
+    return e;
+}
+
+__global__ void sched_x0_kernel(const nlc_sched_desc d) {
+    const int b = blockIdx.y;
+    const SchedScalars s = sched_scalars(d, b);
+    const int n = d.C * d.HW;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        const int c = i / d.HW, p = i - c * d.HW;
+        const float e = sched_eps(d, s, b, c, p);
+        const int64_t o = (int64_t)b * n + i;
+        d.x0[o] = d.xt[o] - s.st * e;                 // pred_xstart, src/schedulers.py:407-409
+        if (d.eps_used) d.eps_used[o] = e;
+    }
+}
+
+__global__ void sched_step_kernel(const nlc_sched_desc d, int* nan_flag) {
+    const int b = blockIdx.y;
+    const SchedScalars s = sched_scalars(d, b);
+    const int n = d.C * d.HW;
+    const float sp2 = s.sp * s.sp;
+    const float dyn = d.dyn_s ? d.dyn_s[b] : 1.f;
+    const float simple_sig = sqrtf(1.0f - d.eta * d.eta);   // math.sqrt(1-eta**2), python double -> f32 scalar
+    bool saw_nan = false;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        const int c = i / d.HW, p = i - c * d.HW;
+        const int64_t o = (int64_t)b * n + i;
+        float e = sched_eps(d, s, b, c, p);
+        const float xt = d.xt[o];
+        float x0 = d.x0[o];                                  // pre-clip x0_hat from phase 0
+        if (d.clip == NLC_CLIP_CLAMP) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        else if (d.clip == NLC_CLIP_DYNAMIC) x0 = fminf(fmaxf(x0, -dyn), dyn) / dyn;
+        if (d.mask) { if (d.mask[(int64_t)c * d.HW + p] != 0.f) x0 = d.known[o]; }
+        float lv = 0.f;
+        if (d.var_mode == NLC_VAR_LEARNED) {
+            const float v = d.eps_out[((int64_t)b * d.Cnet + d.C + c) * d.HW + p];
+            const float frac = (v + 1.0f) / 2.0f;
+            lv = frac * s.max_lv + (1.0f - frac) * s.min_lv;
+        } else if (d.var_mode == NLC_VAR_FIXEDSMALL) lv = s.min_lv;
+        else if (d.var_mode == NLC_VAR_FIXEDLARGE) lv = s.max_lv;
+        float z = d.noise ? d.noise[o] : 0.f;
+        float xp;
+        switch (d.variant) {
+            case NLC_SCHED_DDIM: {
+                float nsig = 0.f;
+                if (d.eta > 0.f) { nsig = d.eta * expf(0.5f * lv) / sqrtf(s.abp); if (!(s.sp > 0.f)) z = 0.f; }
+                else z = 0.f;
+                const float sig = sqrtf(fmaxf(sp2 - nsig * nsig, 0.f));
+                const float nsig2 = sqrtf(sp2 - sig * sig);
+                xp = x0 + sig * e + nsig2 * z;
+            } break;
+            case NLC_SCHED_DDIM_SIMPLE_ORIG:
+            case NLC_SCHED_DDIM_SIMPLE: {
+                if (d.variant == NLC_SCHED_DDIM_SIMPLE_ORIG) e = (xt - x0) / s.st;
+                const float sig = simple_sig * s.sp;
+                xp = x0 + sig * e;
+                if (d.eta > 0.f) xp = xp + (d.eta * s.sp) * z;
+            } break;
+            case NLC_SCHED_DDIM_SIMPLE_DRAG: {
+                e = (xt - x0) / s.st;
+                xp = x0 + s.sp * e;
+                if (d.eta > 0.f) xp = xp + (d.eta * s.sp) * z;
+            } break;
+            case NLC_SCHED_DDPM: {
+                const float nsig = expf(0.5f * lv) / sqrtf(s.abp);
+                const float sig = sqrtf(fmaxf(sp2 - nsig * nsig, 0.f));
+                xp = x0 + sig * e;
+                if (!(s.sp > 0.f)) z = 0.f;
+                xp = xp + nsig * z;
+            } break;
+            case NLC_SCHED_DDIM_ORIG: {
+                e = (xt - x0) / s.st;
+                float nsig = 0.f;
+                if (d.eta > 0.f) { nsig = d.eta * expf(0.5f * lv) / sqrtf(s.abp); if (!(s.sp > 0.f)) z = 0.f; }
+                else z = 0.f;
+                const float sig = sqrtf(fmaxf(sp2 - nsig * nsig, 0.f));
+                xp = x0 + sig * e + nsig * z;
+            } break;
+            default: {   // NLC_SCHED_DDPM_ORIG
+                const float ab = 1.0f / (s.st * s.st + 1.0f);
+                const float abp = s.abp;
+                const float a_t = ab / abp;
+                const float beta_t = 1.0f - a_t;
+                const float zt = xt * sqrtf(ab);
+                const float c1 = beta_t * sqrtf(abp) / (1.0f - ab);
+                const float c2 = (1.0f - abp) * sqrtf(a_t) / (1.0f - ab);
+                const float mean = c1 * x0 + c2 * zt;
+                const float m = (s.sp > 0.f) ? 1.f : 0.f;
+                const float zp = mean + m * expf(0.5f * lv) * z;
+                xp = zp / sqrtf(abp);
+            } break;
+        }
+        d.x0[o] = x0;
+        d.x_prev[o] = xp;
+        if (d.eps_used) d.eps_used[o] = e;
+        saw_nan |= (xp != xp);
+    }
+    if (nan_flag && saw_nan) atomicOr(nan_flag, 1);
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ scale, float scalar,
+                                  float* __restrict__ out, int64_t D) {
+    const int b = blockIdx.y;
+    const float sc = scale ? scale[b] * scalar : scalar;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < D; i += (int64_t)gridDim.x * NT)
+        out[(int64_t)b * D + i] = x[(int64_t)b * D + i] * sc;
+}
+
+int check_sched(const nlc_sched_desc* d, const char* name) {
+    if (!d) { nlc_set_error("%s: null descriptor", name); return NLC_EINVAL; }
+    if (!d->xt || !d->eps_out || !d->sigma_t || !d->sigma_prev || !d->x0) { nlc_set_error("%s: null pointer", name); return NLC_EINVAL; }
+    if (d->B <= 0 || d->C <= 0 || d->HW <= 0 || d->Cnet < d->C) { nlc_set_error("%s: bad dims", name); return NLC_EINVAL; }
+    if (d->B > 65535) { nlc_set_error("%s: B too large", name); return NLC_EINVAL; }
+    if ((int64_t)d->C * d->HW >= (1ll << 31)) { nlc_set_error("%s: sample too large", name); return NLC_EINVAL; }
+    if (d->variant < NLC_SCHED_DDIM || d->variant > NLC_SCHED_DDIM_ORIG) { nlc_set_error("%s: bad variant %d", name, d->variant); return NLC_EINVAL; }
+    if (d->var_mode == NLC_VAR_LEARNED && d->Cnet < 2 * d->C) { nlc_set_error("%s: learned variance needs Cnet >= 2C", name); return NLC_EINVAL; }
+    if ((d->mask == nullptr) != (d->known == nullptr)) { nlc_set_error("%s: mask/known must come together", name); return NLC_EINVAL; }
+    return NLC_OK;
+}
+
+}  // namespace
+
+extern "C" int nlc_row_sumsq(const float* x, float* sumsq, int B, int64_t row_stride, int64_t D, void* stream) {
+    NLC_REQUIRE(x && sumsq && B > 0 && D > 0 && row_stride >= D, "nlc_row_sumsq: bad arguments");
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(B), dim3(RT), 0, (hipStream_t)stream, x, sumsq, row_stride, D);
+    NLC_CHECK_LAUNCH("nlc_row_sumsq");
+    return NLC_OK;
+}
+
+extern "C" int nlc_refine_sigma(const float* sumsq, float sqrt_dim, float norm_max, float norm_min, float sigma_sched,
+                                float sigma_prev_sched, int refine, const float* sigmas, int n_sigmas, int t_sched,
+                                int time_shift, float* sigma_t, float* sigma_prev, float* t, float* c_in, int B,
+                                void* stream) {
+    NLC_REQUIRE(sigma_t && sigma_prev && t && c_in && B > 0, "nlc_refine_sigma: null output / bad B");
+    NLC_REQUIRE(!refine || (sumsq && sigmas && n_sigmas > 0), "nlc_refine_sigma: refine needs sumsq and the sigma table");
+    hipLaunchKernelGGL(refine_sigma_kernel, dim3(1), dim3(RT), 0, (hipStream_t)stream, sumsq, sqrt_dim, norm_max, norm_min,
+                       sigma_sched, sigma_prev_sched, refine, sigmas, n_sigmas, t_sched, time_shift, sigma_t, sigma_prev, t,
+                       c_in, B);
+    NLC_CHECK_LAUNCH("nlc_refine_sigma");
+    return NLC_OK;
+}
+
+extern "C" int nlc_sigma_correct(const float* r, int partial, const float* sigmas, int n_sigmas, float* sigma_t,
+                                 float* sigma_prev, float* t, float* c_in, int B, void* stream) {
+    NLC_REQUIRE(r && sigmas && sigma_t && sigma_prev && t && c_in && B > 0 && n_sigmas > 0, "nlc_sigma_correct: bad arguments");
+    hipLaunchKernelGGL(sigma_correct_kernel, dim3(cdiv(B, NT)), dim3(NT), 0, (hipStream_t)stream, r, partial, sigmas, n_sigmas,
+                       sigma_t, sigma_prev, t, c_in, B);
+    NLC_CHECK_LAUNCH("nlc_sigma_correct");
+    return NLC_OK;
+}
+
+extern "C" int nlc_dynamic_threshold(const float* x0_hat, float q, float max_value, float* s_out, int B, int64_t D,
+                                     void* stream) {
+    NLC_REQUIRE(x0_hat && s_out && B > 0 && D > 1, "nlc_dynamic_threshold: bad arguments");
+    NLC_REQUIRE(q >= 0.f && q <= 1.f, "nlc_dynamic_threshold: q out of range");
+    NLC_REQUIRE(D < (1ll << 24), "nlc_dynamic_threshold: D too large for exact f32 rank arithmetic");
+    hipLaunchKernelGGL(quantile_kernel, dim3(B), dim3(RT), 0, (hipStream_t)stream, x0_hat, q, max_value, s_out, D);
+    NLC_CHECK_LAUNCH("nlc_dynamic_threshold");
+    return NLC_OK;
+}
+
+extern "C" int nlc_sched_x0(const nlc_sched_desc* d, void* stream) {
+    int rc = check_sched(d, "nlc_sched_x0"); if (rc) return rc;
+    int gx = cdiv((int64_t)d->C * d->HW, NT * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(sched_x0_kernel, dim3(gx, d->B), dim3(NT), 0, (hipStream_t)stream, *d);
+    NLC_CHECK_LAUNCH("nlc_sched_x0");
+    return NLC_OK;
+}
+
+extern "C" int nlc_sched_step(const nlc_sched_desc* d, int* nan_flag, void* stream) {
+    int rc = check_sched(d, "nlc_sched_step"); if (rc) return rc;
+    NLC_REQUIRE(d->x_prev, "nlc_sched_step: null x_prev");
+    NLC_REQUIRE(d->clip >= NLC_CLIP_NONE && d->clip <= NLC_CLIP_DYNAMIC, "nlc_sched_step: bad clip %d", d->clip);
+    NLC_REQUIRE(d->clip != NLC_CLIP_DYNAMIC || d->dyn_s, "nlc_sched_step: dynamic clip needs dyn_s");
+    NLC_REQUIRE(d->var_mode >= NLC_VAR_NONE && d->var_mode <= NLC_VAR_LEARNED, "nlc_sched_step: bad var_mode %d", d->var_mode);
+    const bool needs_noise = (d->variant == NLC_SCHED_DDPM || d->variant == NLC_SCHED_DDPM_ORIG || d->eta > 0.f);
+    NLC_REQUIRE(!needs_noise || d->noise, "nlc_sched_step: this variant/eta needs a noise tensor");
+    NLC_REQUIRE(!needs_noise || d->var_mode != NLC_VAR_NONE || d->variant == NLC_SCHED_DDIM_SIMPLE ||
+                    d->variant == NLC_SCHED_DDIM_SIMPLE_ORIG || d->variant == NLC_SCHED_DDIM_SIMPLE_DRAG,
+                "nlc_sched_step: stochastic variant with sampler_var 'none' (the reference raises here too)");
+    int gx = cdiv((int64_t)d->C * d->HW, NT * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(sched_step_kernel, dim3(gx, d->B), dim3(NT), 0, (hipStream_t)stream, *d, nan_flag);
+    NLC_CHECK_LAUNCH("nlc_sched_step");
+    return NLC_OK;
+}
+
+extern "C" int nlc_scale_rows(const float* x, const float* scale, float scalar, float* out, int B, int64_t D, void* stream) {
+    NLC_REQUIRE(x && out && B > 0 && D > 0 && B <= 65535, "nlc_scale_rows: bad arguments");
+    int gx = cdiv(D, NT * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(gx, B), dim3(NT), 0, (hipStream_t)stream, x, scale, scalar, out, D);
+    NLC_CHECK_LAUNCH("nlc_scale_rows");
+    return NLC_OK;
+}

@@ -1,0 +1,342 @@
+"""Tensor -> raw-pointer shims over the C ABI (include/nlc_hip.h).
+
+PyTorch is used here only as the owner of device memory and of the HIP stream; every
+arithmetic op below is a hand-written gfx950 kernel in libnlc_hip.so.  Activations are
+channels-last ``[B, H, W, C]`` tensors in the compute dtype (torch.float32 or torch.bfloat16).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _ext
+from ._ext import (ACT_GELU, ACT_NONE, ACT_SILU, NLC_BF16, NLC_F32, OUT_NCHW_F32, OUT_NHWC,
+                   ConvDesc, SchedDesc, check)
+
+
+def dtype_enum(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return NLC_F32
+    if dtype == torch.bfloat16:
+        return NLC_BF16
+    raise TypeError(f"compute dtype must be float32 or bfloat16, got {dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise _ext.NlcError(f"{name}: tensor must live on the GPU (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+# --------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------
+@dataclass
+class PackedConv:
+    """A convolution / linear weight packed for nlc_conv2d: [Cout_pad][KH*KW][Cin_pad]."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]      # f32 [Cout] or None
+    Cin: int
+    Cout: int
+    KH: int
+    KW: int
+    Cin_pad: int
+    Cout_pad: int
+    dtype: torch.dtype
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype, device,
+              row_perm: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+              col_perm: Optional[torch.Tensor] = None) -> PackedConv:
+    """Pack a torch-layout weight ([Cout,Cin,KH,KW], [Cout,Cin,K] or [Cout,Cin]) once at load time.
+
+    row_perm / row_scale reorder and scale output channels (used to bring the reference's qkv
+    channel orders into the canonical [3][H][D] order and to fold the attention scale);
+    col_perm reorders input features (NCHW-flatten -> NHWC-flatten for the sigma head).
+    """
+    w = weight.detach().to(torch.float32).cpu()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, :, None]
+    b = None if bias is None else bias.detach().to(torch.float32).cpu().clone()
+    if col_perm is not None:
+        w = w[:, col_perm]
+    if row_perm is not None:
+        w = w[row_perm]
+        if b is not None:
+            b = b[row_perm]
+    if row_scale is not None:
+        w = w * row_scale.view(-1, 1, 1, 1)
+        if b is not None:
+            b = b * row_scale
+    Cout, Cin, KH, KW = w.shape
+    cout_mult, cin_mult = _ext.pack_dims(dtype_enum(dtype))
+    Cin_pad, Cout_pad = _round_up(Cin, cin_mult), _round_up(Cout, cout_mult)
+    packed = torch.zeros(Cout_pad, KH * KW, Cin_pad, dtype=torch.float32)
+    packed[:Cout, :, :Cin] = w.permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin)
+    return PackedConv(w=packed.to(device=device, dtype=dtype).contiguous(),
+                      bias=None if b is None else b.to(device).contiguous(),
+                      Cin=Cin, Cout=Cout, KH=KH, KW=KW, Cin_pad=Cin_pad, Cout_pad=Cout_pad, dtype=dtype)
+
+
+# --------------------------------------------------------------------------------------
+# kernels
+# --------------------------------------------------------------------------------------
+def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
+           pad: Optional[tuple] = None, out_hw: Optional[tuple] = None, upsample2x: bool = False,
+           emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
+           act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True) -> torch.Tensor:
+    """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1)."""
+    lib = _ext.load()
+    dt = pw.dtype
+    linear = x0.dim() == 2
+    if linear:
+        x0 = x0.view(x0.shape[0], 1, 1, x0.shape[1])
+    _need(x0, dt, "conv2d x0")
+    B, Hin, Win, C0 = x0.shape
+    C1 = 0
+    if x1 is not None:
+        _need(x1, dt, "conv2d x1")
+        if tuple(x1.shape[:3]) != (B, Hin, Win):
+            raise ValueError("conv2d: x1 spatial shape mismatch")
+        C1 = x1.shape[3]
+    if C0 + C1 != pw.Cin:
+        raise ValueError(f"conv2d: input channels {C0}+{C1} != weight Cin {pw.Cin}")
+    if pad is None:
+        pad = (pw.KH // 2, pw.KW // 2)
+    HL, WL = (2 * Hin, 2 * Win) if upsample2x else (Hin, Win)
+    if out_hw is None:
+        Hout = (HL + 2 * pad[0] - pw.KH) // stride + 1
+        Wout = (WL + 2 * pad[1] - pw.KW) // stride + 1
+    else:
+        Hout, Wout = out_hw
+    if out_nchw_f32:
+        out = torch.empty(B, pw.Cout, Hout, Wout, device=x0.device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, Hout, Wout, pw.Cout, device=x0.device, dtype=dt)
+    if res is not None:
+        _need(res, dt, "conv2d res")
+        if res.numel() != B * Hout * Wout * pw.Cout:
+            raise ValueError("conv2d: residual shape mismatch")
+    emb_stride = 0
+    if emb is not None:
+        _need(emb, torch.float32, "conv2d emb")
+        if emb.shape[0] != B or emb.shape[-1] < pw.Cout:
+            raise ValueError("conv2d: emb shape mismatch")
+        emb_stride = emb.stride(0)
+    d = ConvDesc(x0=x0.data_ptr(), x1=_ptr(x1), C0=C0, C1=C1, B=B, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout,
+                 Cout=pw.Cout, KH=pw.KH, KW=pw.KW, stride=stride, pad_t=pad[0], pad_l=pad[1],
+                 upsample2x=1 if upsample2x else 0, w=pw.w.data_ptr(), Cin_pad=pw.Cin_pad, Cout_pad=pw.Cout_pad,
+                 bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
+                 out_scale=out_scale, act=act, out=out.data_ptr(),
+                 out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC)
+    check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
+    if linear and not out_nchw_f32:
+        out = out.view(B, pw.Cout)
+    return out
+
+
+def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
+               in_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """First-layer conv (Cin<=4) straight from the f32 NCHW sampler state; w: [Cout][KH*KW][Cin] f32."""
+    lib = _ext.load()
+    _need(x_nchw, torch.float32, "conv_first x")
+    B, Cin, H, W = x_nchw.shape
+    Cout, taps, cin_w = w.shape
+    k = int(round(math.sqrt(taps)))
+    if cin_w != Cin or k * k != taps:
+        raise ValueError("conv_first: weight shape mismatch")
+    out = torch.empty(B, H, W, Cout, device=x_nchw.device, dtype=dtype)
+    check(lib.nlc_conv_first(x_nchw.data_ptr(), _ptr(in_scale), w.data_ptr(), _ptr(bias), out.data_ptr(),
+                             B, Cin, H, W, Cout, k, k, dtype_enum(dtype), _stream()), "nlc_conv_first")
+    return out
+
+
+_gn_ws = {}
+
+
+def _gn_workspace(device, nbytes: int) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4 + 1, 1 << 16), device=device, dtype=torch.float32)
+        _gn_ws[key] = ws
+    return ws
+
+
+def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], *, groups: int,
+              eps: float, silu: bool, x1: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+              shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm(+FiLM)(+SiLU) over cat(x0,x1) on [B,H,W,C] / [B,T,C]; output has C0+C1 channels."""
+    lib = _ext.load()
+    dt = x0.dtype
+    _need(x0, dt, "groupnorm x0")
+    B, C0 = x0.shape[0], x0.shape[-1]
+    HW = x0.numel() // (B * C0)
+    C1 = 0
+    if x1 is not None:
+        _need(x1, dt, "groupnorm x1")
+        C1 = x1.shape[-1]
+    Ctot = C0 + C1
+    out = torch.empty(*x0.shape[:-1], Ctot, device=x0.device, dtype=dt)
+    ss_stride = 0
+    if scale is not None:
+        _need(scale, torch.float32, "groupnorm scale")
+        ss_stride = scale.stride(0)
+        if shift is None or shift.stride(0) != ss_stride:
+            raise ValueError("groupnorm: scale/shift must share a row stride")
+    ws = _gn_workspace(x0.device, lib.nlc_groupnorm_workspace_bytes(B, HW, Ctot, groups))
+    check(lib.nlc_groupnorm(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
+                            _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(), ws.data_ptr(),
+                            dtype_enum(dt), _stream()), "nlc_groupnorm")
+    return out
+
+
+def attention(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """qkv: [B,T,3*H*D] laid out [3][H][D]; returns [B,T,H*D]."""
+    lib = _ext.load()
+    _need(qkv, qkv.dtype, "attention qkv")
+    B, T, C3 = qkv.shape
+    D = C3 // (3 * heads)
+    out = torch.empty(B, T, heads * D, device=qkv.device, dtype=qkv.dtype)
+    check(lib.nlc_attention(qkv.data_ptr(), out.data_ptr(), B, T, heads, D, dtype_enum(qkv.dtype), _stream()),
+          "nlc_attention")
+    return out
+
+
+def avgpool2x2(x: torch.Tensor) -> torch.Tensor:
+    lib = _ext.load()
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, H // 2, W // 2, Cc, device=x.device, dtype=x.dtype)
+    check(lib.nlc_avgpool2x2(_need(x, x.dtype, "avgpool x").data_ptr(), out.data_ptr(), B, H, W, Cc,
+                             dtype_enum(x.dtype), _stream()), "nlc_avgpool2x2")
+    return out
+
+
+def upsample2x(x: torch.Tensor) -> torch.Tensor:
+    lib = _ext.load()
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, 2 * H, 2 * W, Cc, device=x.device, dtype=x.dtype)
+    check(lib.nlc_upsample2x(_need(x, x.dtype, "upsample x").data_ptr(), out.data_ptr(), B, H, W, Cc,
+                             dtype_enum(x.dtype), _stream()), "nlc_upsample2x")
+    return out
+
+
+def pad_rb(x: torch.Tensor) -> torch.Tensor:
+    lib = _ext.load()
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, H + 1, W + 1, Cc, device=x.device, dtype=x.dtype)
+    check(lib.nlc_pad_rb(_need(x, x.dtype, "pad x").data_ptr(), out.data_ptr(), B, H, W, Cc,
+                         dtype_enum(x.dtype), _stream()), "nlc_pad_rb")
+    return out
+
+
+def nhwc_to_nchw_f32(x: torch.Tensor) -> torch.Tensor:
+    lib = _ext.load()
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, Cc, H, W, device=x.device, dtype=torch.float32)
+    check(lib.nlc_nhwc_to_nchw_f32(_need(x, x.dtype, "nhwc_to_nchw x").data_ptr(), out.data_ptr(), B, H, W, Cc,
+                                   dtype_enum(x.dtype), _stream()), "nlc_nhwc_to_nchw_f32")
+    return out
+
+
+def nchw_f32_to_nhwc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    lib = _ext.load()
+    _need(x, torch.float32, "nchw_to_nhwc x")
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, H, W, Cc, device=x.device, dtype=dtype)
+    check(lib.nlc_nchw_f32_to_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, Cc, dtype_enum(dtype), _stream()),
+          "nlc_nchw_f32_to_nhwc")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, freqs: torch.Tensor, sin_first: bool) -> torch.Tensor:
+    lib = _ext.load()
+    _need(t, torch.float32, "timestep_embedding t")
+    _need(freqs, torch.float32, "timestep_embedding freqs")
+    B, half = t.shape[0], freqs.shape[0]
+    out = torch.empty(B, 2 * half, device=t.device, dtype=torch.float32)
+    check(lib.nlc_timestep_embedding(t.data_ptr(), freqs.data_ptr(), out.data_ptr(), B, 2 * half,
+                                     1 if sin_first else 0, _stream()), "nlc_timestep_embedding")
+    return out
+
+
+# ---- sampler state ---------------------------------------------------------------------
+def row_sumsq(x: torch.Tensor, d_used: Optional[int] = None) -> torch.Tensor:
+    lib = _ext.load()
+    _need(x, torch.float32, "row_sumsq x")
+    B = x.shape[0]
+    stride = x.numel() // B
+    D = stride if d_used is None else d_used
+    out = torch.empty(B, device=x.device, dtype=torch.float32)
+    check(lib.nlc_row_sumsq(x.data_ptr(), out.data_ptr(), B, stride, D, _stream()), "nlc_row_sumsq")
+    return out
+
+
+def refine_sigma(sumsq, sqrt_dim, norm_max, norm_min, sigma_sched, sigma_prev_sched, refine, sigmas, t_sched,
+                 time_shift, sigma_t, sigma_prev, t, c_in):
+    lib = _ext.load()
+    B = sigma_t.shape[0]
+    check(lib.nlc_refine_sigma(_ptr(sumsq), sqrt_dim, norm_max, norm_min, sigma_sched, sigma_prev_sched,
+                               1 if refine else 0, _ptr(sigmas), 0 if sigmas is None else sigmas.shape[0],
+                               int(t_sched), int(time_shift), sigma_t.data_ptr(), sigma_prev.data_ptr(),
+                               t.data_ptr(), c_in.data_ptr(), B, _stream()), "nlc_refine_sigma")
+
+
+def sigma_correct(r, partial, sigmas, sigma_t, sigma_prev, t, c_in):
+    lib = _ext.load()
+    _need(r, torch.float32, "sigma_correct r")
+    B = sigma_t.shape[0]
+    check(lib.nlc_sigma_correct(r.data_ptr(), 1 if partial else 0, sigmas.data_ptr(), sigmas.shape[0],
+                                sigma_t.data_ptr(), sigma_prev.data_ptr(), t.data_ptr(), c_in.data_ptr(), B,
+                                _stream()), "nlc_sigma_correct")
+
+
+def dynamic_threshold(x0_hat: torch.Tensor, q: float, max_value: float) -> torch.Tensor:
+    lib = _ext.load()
+    _need(x0_hat, torch.float32, "dynamic_threshold x")
+    B = x0_hat.shape[0]
+    D = x0_hat.numel() // B
+    out = torch.empty(B, device=x0_hat.device, dtype=torch.float32)
+    check(lib.nlc_dynamic_threshold(x0_hat.data_ptr(), q, max_value, out.data_ptr(), B, D, _stream()),
+          "nlc_dynamic_threshold")
+    return out
+
+
+def sched_x0(desc: SchedDesc):
+    check(_ext.load().nlc_sched_x0(C.byref(desc), _stream()), "nlc_sched_x0")
+
+
+def sched_step(desc: SchedDesc, nan_flag: Optional[torch.Tensor] = None):
+    check(_ext.load().nlc_sched_step(C.byref(desc), _ptr(nan_flag), _stream()), "nlc_sched_step")
+
+
+def scale_rows(x: torch.Tensor, scale: Optional[torch.Tensor], scalar: float = 1.0) -> torch.Tensor:
+    lib = _ext.load()
+    _need(x, torch.float32, "scale_rows x")
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    check(lib.nlc_scale_rows(x.data_ptr(), _ptr(scale), scalar, out.data_ptr(), B, x.numel() // B, _stream()),
+          "nlc_scale_rows")
+    return out

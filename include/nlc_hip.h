@@ -1,0 +1,215 @@
+/*
+ * nlc_hip.h — C ABI of libnlc_hip.so, the MI355X (gfx950) kernel library behind the
+ * DDIM/EDM + noise-level-correction (NLC) sampling hot path.
+ *
+ * The reference (Walleclipse/Diffusion-NLC) is pure Python on PyTorch and has no FFI
+ * of its own; every entry point below replaces a stock torch.nn.functional call (or a
+ * short chain of them) that the reference makes on the sampling path.  The reference
+ * call site each one stands in for is cited as  file:line  under /root/reference.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative NLC_E* code; nlc_last_error()
+ *    gives a thread-local message.  Nothing allocates, nothing synchronises the host.
+ *  - All pointers are BORROWED device pointers (hipMalloc'ed / torch caching allocator).
+ *    The caller keeps them alive until `stream` has passed the launch.
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ *  - dtype: NLC_F32 (exact f32 MFMA path) or NLC_BF16 (bf16 operands, f32 accumulate).
+ *  - Activations are channels-last: [B][H][W][C] ("NHWC"); token tensors are [B][T][C].
+ *    Weights are pre-packed by the host into [Cout_pad][KH*KW][Cin_pad] (see
+ *    nlc_conv_pack_dims) in the compute dtype.
+ */
+#ifndef NLC_HIP_H
+#define NLC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLC_ABI_VERSION 1
+
+enum { NLC_F32 = 0, NLC_BF16 = 1 };
+enum { NLC_OK = 0, NLC_EINVAL = -1, NLC_ELAUNCH = -2, NLC_EUNSUPPORTED = -3 };
+enum { NLC_ACT_NONE = 0, NLC_ACT_SILU = 1, NLC_ACT_GELU = 2 };
+enum { NLC_OUT_NHWC = 0, NLC_OUT_NCHW_F32 = 1 };
+/* scheduler variants of nlc_sched_step (reference src/schedulers.py:425-627) */
+enum {
+    NLC_SCHED_DDIM = 0,            /* DDIM_Scheduler.pred_xprev             :432-449 */
+    NLC_SCHED_DDIM_SIMPLE = 1,     /* DDIM_simple_Scheduler.pred_xprev      :465-473 */
+    NLC_SCHED_DDIM_SIMPLE_ORIG = 2,/* DDIM_simple_orig_Scheduler.pred_xprev :487-496 */
+    NLC_SCHED_DDIM_SIMPLE_DRAG = 3,/* DDIM_simple_drag_Scheduler.pred_xprev :505-514 */
+    NLC_SCHED_DDPM = 4,            /* DDPM_Scheduler.pred_xprev             :548-562 */
+    NLC_SCHED_DDPM_ORIG = 5,       /* DDPM_orig_Scheduler.pred_xprev        :581-599 */
+    NLC_SCHED_DDIM_ORIG = 6        /* DDIM_orig_Scheduler.pred_xprev        :609-627 */
+};
+enum { NLC_CLIP_NONE = 0, NLC_CLIP_CLAMP = 1, NLC_CLIP_DYNAMIC = 2 };
+enum { NLC_VAR_NONE = 0, NLC_VAR_FIXEDSMALL = 1, NLC_VAR_FIXEDLARGE = 2, NLC_VAR_LEARNED = 3 };
+
+int nlc_version(void);
+const char* nlc_last_error(void);
+
+/* Tile geometry the host needs to pack weights: Cout is padded to a multiple of
+ * *cout_mult rows and Cin to a multiple of *cin_mult elements (zero filled). */
+int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution / linear as one implicit-GEMM MFMA kernel.
+ * Replaces torch.nn.functional.conv2d / conv1d(k=1) / linear at
+ *   src/unet_adm.py:98,131-133,185,211,222,286,294,617 ; src/unet_simple.py:41,61,87,96,109,143-162,226,296
+ *   src/edm_networks.py:42,95 ; nn.Linear at src/unet_adm.py:474-476,201,1055,1058
+ * together with the elementwise work the reference does right after it:
+ *   + bias, + per-(image,channel) embedding add (unet_simple.py:121, edm_networks.py:192),
+ *   + residual add (unet_adm.py:256,305), * out_scale (edm_networks.py:196), activation.
+ * Input may be the channel-concatenation of two NHWC tensors (th.cat at unet_adm.py:662)
+ * and may be read through a nearest-neighbour 2x upsample (F.interpolate, unet_adm.py:107).
+ * ---------------------------------------------------------------------------------- */
+typedef struct nlc_conv_desc {
+    const void* x0;      /* [B][Hin][Win][C0]                                   */
+    const void* x1;      /* [B][Hin][Win][C1] or NULL; logical input = cat(x0,x1)*/
+    int32_t C0, C1;
+    int32_t B, Hin, Win; /* physical input size (before the optional 2x upsample) */
+    int32_t Hout, Wout;
+    int32_t Cout;        /* real output channels                                 */
+    int32_t KH, KW, stride, pad_t, pad_l;
+    int32_t upsample2x;  /* 1: taps index a virtual (2Hin x 2Win) nearest-upsampled input */
+    const void* w;       /* packed [Cout_pad][KH*KW][Cin_pad], compute dtype      */
+    int32_t Cin_pad, Cout_pad;
+    const float* bias;   /* [Cout] f32 or NULL                                   */
+    const float* emb;    /* [B][emb_stride] f32 or NULL: out[b,:,:,n] += emb[b][n] */
+    int32_t emb_stride;
+    const void* res;     /* [B][Hout][Wout][Cout] compute dtype or NULL          */
+    float out_scale;     /* applied after bias/emb/res, before act               */
+    int32_t act;         /* NLC_ACT_*                                            */
+    void* out;           /* NLC_OUT_NHWC: compute dtype; NLC_OUT_NCHW_F32: float */
+    int32_t out_mode;
+} nlc_conv_desc;
+
+int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
+
+/* First-layer convolution for tiny Cin (<=4): reads the sampler state in the reference's
+ * own layout (NCHW f32), applies the per-sample input scale c_in[b] (convert_coordinate,
+ * src/experiments.py:273-282; c_in of :782,796), and writes NHWC compute dtype.
+ * Replaces conv_nd at src/unet_adm.py:484, conv_in at src/unet_simple.py:226,
+ * enc '<res>_conv' at src/edm_networks.py:790.   w: [Cout][KH*KW][Cin] f32. */
+int nlc_conv_first(const float* x_nchw, const float* in_scale /*[B] or NULL*/,
+                   const float* w, const float* bias, void* out_nhwc,
+                   int B, int Cin, int H, int W, int Cout, int KH, int KW,
+                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm (+ optional FiLM scale/shift, + optional SiLU), statistics in f32.
+ * Replaces GroupNorm32 + SiLU (src/nn_util.py:17-19, src/unet_adm.py:182-184,206-208,
+ * 248-252), Normalize+nonlinearity (src/unet_simple.py:32,117-118,123-124) and
+ * GroupNorm+silu (src/edm_networks.py:113-116,185,192).  Input may be cat(x0,x1).
+ *   y = act( ((x-mean)*rstd*gamma+beta) * (1+scale[b,c]) + shift[b,c] )
+ * workspace: at least nlc_groupnorm_workspace_bytes() bytes, f32 aligned.
+ * ---------------------------------------------------------------------------------- */
+int64_t nlc_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int HW,
+                  int groups, float eps, const float* gamma, const float* beta,
+                  const float* scale, const float* shift, int ss_stride,
+                  int silu, void* out, void* workspace, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-head softmax attention on token-major tensors (flash style, no TxT matrix in HBM).
+ * Replaces QKVAttentionLegacy/QKVAttention.forward (src/unet_adm.py:337-354,370-389),
+ * AttnBlock bmm/softmax/bmm (src/unet_simple.py:172-185) and AttentionOp + einsum
+ * (src/edm_networks.py:126-130,199-203).  The per-family q/k scaling is folded into the
+ * qkv projection weights by the host, so here  out = softmax(q k^T) v  exactly.
+ *   qkv: [B][T][3][H][D]   out: [B][T][H][D]   (compute dtype), softmax in f32.
+ * ---------------------------------------------------------------------------------- */
+int nlc_attention(const void* qkv, void* out, int B, int T, int H, int D,
+                  int dtype, void* stream);
+
+/* ---- resampling on NHWC (src/unet_adm.py:107,136 ; src/unet_simple.py:48,73 ;
+ *      edm_networks.py:88-93 with resample_filter [1,1]) ---- */
+int nlc_avgpool2x2(const void* x, void* out, int B, int H, int W, int C, int dtype, void* stream);
+int nlc_upsample2x(const void* x, void* out, int B, int H, int W, int C, int dtype, void* stream);
+/* zero-pad right/bottom by one pixel (F.pad (0,1,0,1), src/unet_simple.py:69-70) */
+int nlc_pad_rb(const void* x, void* out, int B, int H, int W, int C, int dtype, void* stream);
+/* NHWC compute dtype  ->  NCHW f32 (feature map handed to the sigma net's callers) */
+int nlc_nhwc_to_nchw_f32(const void* x, float* out, int B, int H, int W, int C, int dtype, void* stream);
+/* NCHW f32 -> NHWC compute dtype */
+int nlc_nchw_f32_to_nhwc(const float* x, void* out, int B, int H, int W, int C, int dtype, void* stream);
+
+/* ---- sinusoidal timestep embeddings, f32 out [B][dim]: out = [cos(t*f) || sin(t*f)] or, with
+ *  sin_first, [sin || cos].  freqs[dim/2] is computed on the host with the reference's own
+ *  formula so that t*f is bit-identical:
+ *    ADM    src/nn_util.py:103-121      cos||sin, f = exp(-ln(1e4) i/half)
+ *    simple src/unet_simple.py:6-24     sin||cos, f = exp(-i ln(1e4)/(half-1))
+ *    EDM    src/edm_networks.py:219-225 + swap at :838 -> sin||cos, f = (1e-4)^(i/(half-1)) ---- */
+int nlc_timestep_embedding(const float* t, const float* freqs, float* out, int B, int dim,
+                           int sin_first, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Sampler-state kernels (per-sample, f32, NCHW state exactly as the reference keeps it).
+ * The per-sample scalars sigma_t[b], sigma_prev[b], t[b], c_in[b] live in device arrays.
+ * ---------------------------------------------------------------------------------- */
+/* sumsq[b] = sum_{d<D} x[b*row_stride+d]^2  (utils.vector_norm squared, src/utils.py:7-9).
+ * row_stride > D selects the first D elements of each row (the eps channels of a 2C-channel
+ * network output, src/experiments.py:451-458). */
+int nlc_row_sumsq(const float* x, float* sumsq, int B, int64_t row_stride, int64_t D, void* stream);
+
+/* refine_prior_sigma + timestep lookup (src/experiments.py:401-419):
+ *   refine: n = sqrt(sumsq[b])/sqrt_dim ; sigma_t = clamp(sigma_sched, max(n-norm_max,0), n+norm_min)
+ *           t = searchsorted_left(sigmas, sigma_t) ; if min_b t > 0: t -= time_shift
+ *   else  : sigma_t = sigma_sched, t = t_sched
+ *   always: sigma_prev = sigma_prev_sched ; t = clamp(t,0,1000) (f32) ; c_in = sqrt(1/(sigma_t^2+1))
+ *   norm_max / norm_min are already divided by sqrt(dim) (set_norm_maxmin, :176-184).
+ *   sigmas: the scheduler's ascending table (src/schedulers.py:134). */
+int nlc_refine_sigma(const float* sumsq, float sqrt_dim, float norm_max, float norm_min,
+                     float sigma_sched, float sigma_prev_sched, int refine,
+                     const float* sigmas, int n_sigmas, int t_sched, int time_shift,
+                     float* sigma_t, float* sigma_prev, float* t, float* c_in,
+                     int B, void* stream);
+
+/* NLC correction (src/experiments.py:424-431): sigma_hat = sigma_t*(1+r[b]),
+ * sigma_prev_hat = sigma_hat*(sigma_prev/sigma_t) (skipped when partial != 0, style
+ * 'pred_partial'), t = clamp(searchsorted_left(sigmas, sigma_hat),0,1000), c_in updated. */
+int nlc_sigma_correct(const float* r, int partial, const float* sigmas, int n_sigmas,
+                      float* sigma_t, float* sigma_prev, float* t, float* c_in,
+                      int B, void* stream);
+
+/* s[b] = clamp(quantile_q(|x[b,:]|), 1, max_value) with torch.quantile's linear
+ * interpolation and f32 rank arithmetic (src/experiments.py:190-199), exact radix select. */
+int nlc_dynamic_threshold(const float* x0_hat, float q, float max_value, float* s_out,
+                          int B, int64_t D, void* stream);
+
+/* One fused scheduler update on the NCHW f32 state (src/experiments.py:360-370,
+ * src/schedulers.py:367-390,407-449 and the variants listed in the NLC_SCHED_* enum).
+ *   eps_out: network output [B][Cnet][H][W]; channels [0,C) are eps, [C,2C) the learned
+ *            log-variance fraction when var_mode == NLC_VAR_LEARNED (learn_sigma).
+ *   eps_norm_sumsq: if non-NULL, eps <- sqrt(D)*eps/max(sqrt(sumsq[b]),1e-12)
+ *                   (utils.normalize, src/utils.py:11-16).
+ *   nlc_sched_x0  : x0 <- xt - sigma_t*eps                     (pred_xstart, pre-clip)
+ *   nlc_sched_step: x0 <- clip(x0) [none | clamp(-1,1) | clamp(-s,s)/s with s = dyn_s[b]],
+ *                   optional inpainting projection x0 <- known where mask != 0,
+ *                   x_prev <- pred_xprev(x0, eps, ...) for the chosen variant.
+ *   noise: host-ordered N(0,1) draw [B][C][H][W] (needed when eta > 0 or DDPM variants).
+ *   nan_flag: optional device int, OR-ed with 1 if any x_prev is NaN (the reference's
+ *             torch.isnan(xt).any() early break, src/experiments.py:389).
+ */
+typedef struct nlc_sched_desc {
+    const float* xt; const float* eps_out; const float* noise;
+    const float* known; const float* mask;           /* [B][C][HW] / [C][HW], or both NULL */
+    const float* sigma_t; const float* sigma_prev;   /* [B] */
+    const float* eps_norm_sumsq;  /* [B] or NULL */
+    const float* dyn_s;           /* [B] or NULL (dynamic threshold value) */
+    float* x0; float* x_prev; float* eps_used;       /* eps_used may be NULL */
+    int32_t B, C, Cnet, HW;
+    int32_t variant, clip, var_mode;
+    float eta, min_var_coef;
+} nlc_sched_desc;
+int nlc_sched_x0(const nlc_sched_desc* d, void* stream);
+int nlc_sched_step(const nlc_sched_desc* d, int* nan_flag, void* stream);
+
+/* out[b,:] = x[b,:] * scale[b] * scalar  (scale may be NULL).  inv_convert_coordinate,
+ * src/experiments.py:284-293: xt = z * sqrt(sigma0^2+1). */
+int nlc_scale_rows(const float* x, const float* scale /*[B]*/, float scalar, float* out,
+                   int B, int64_t D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLC_HIP_H */

@@ -1,0 +1,251 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch-CPU f32 ops.
+
+Tolerances: f32 path 2e-4 relative-to-scale (different summation order only); bf16 path is
+compared with the same op evaluated in f32 on bf16-rounded operands, tolerance 2e-2 (output
+rounding to bf16 + f32-accumulate order).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 2e-2
+
+
+def _rt(x, dtype):
+    """round-trip through the compute dtype (what the kernel actually sees)."""
+    return x.to(dtype).to(torch.float32)
+
+
+def _nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(device=_dev(), dtype=dtype)
+
+
+def _close(got, ref, tol, what=""):
+    got = got.detach().float().cpu()
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item() / scale
+    assert err <= tol, f"{what}: max rel-to-scale err {err:.3e} > {tol:.1e} (scale {scale:.3e})"
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, extras
+    dict(B=2, Cin=64, H=16, W=16, Cout=128, k=3),
+    dict(B=1, Cin=32, H=9, W=7, Cout=6, k=3),                        # ragged spatial, tiny Cout, Cin < k-block
+    dict(B=2, Cin=96, H=8, W=8, Cout=200, k=3, bias=False),          # Cin, Cout not tile multiples
+    dict(B=3, Cin=128, H=4, W=4, Cout=128, k=1),                     # 1x1
+    dict(B=2, Cin=64, H=16, W=16, Cout=64, k=3, stride=2, pad=1),    # ADM Downsample conv (unet_adm.py:131)
+    dict(B=2, Cin=64, H=16, W=16, Cout=64, k=3, stride=2, pad=0, asym=True),   # simple Downsample (unet_simple.py:67-71)
+    dict(B=2, Cin=64, H=8, W=8, Cout=64, k=3, ups=True),             # conv after nearest 2x (unet_adm.py:107-109)
+    dict(B=2, Cin=64, H=8, W=8, Cout=96, k=3, split=24),             # cat(x0, x1) input, 24 + 40 channels
+    dict(B=2, Cin=160, H=8, W=8, Cout=64, k=1, split=96),            # 1x1 skip over a concat, crosses a k-block
+    dict(B=2, Cin=64, H=8, W=8, Cout=64, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
+    dict(B=2, Cin=64, H=8, W=8, Cout=64, k=3, act="silu"),
+    dict(B=2, Cin=64, H=8, W=8, Cout=16, k=3, act="gelu", nchw=True),
+    dict(B=1, Cin=256, H=32, W=32, Cout=256, k=3),                   # multi-tile M and N
+    dict(B=2, Cin=64, H=2, W=2, Cout=64, k=3),                       # 2x2 image (sigma net tail)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d(case, dtype):
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(hash(str(case)) % (1 << 31))
+    B, Cin, H, W, Cout, k = (case[x] for x in ("B", "Cin", "H", "W", "Cout", "k"))
+    stride, pad = case.get("stride", 1), case.get("pad", k // 2)
+    per = 4 if dtype == torch.float32 else 8
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) * 0.1 if case.get("bias", True) else None
+    xr, wr = _rt(x, dtype), _rt(w, dtype)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if case.get("ups") else xr
+    if case.get("asym"):
+        xin = F.pad(xin, (0, 1, 0, 1))
+    ref = F.conv2d(xin, wr, b, stride=stride, padding=pad)
+    emb = res = None
+    if case.get("emb"):
+        emb = torch.randn(B, Cout + 8, generator=g)
+        ref = ref + emb[:, :Cout, None, None]
+    if case.get("res"):
+        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + _rt(res, dtype)
+    ref = ref * case.get("scale", 1.0)
+    act = {"silu": 1, "gelu": 2}.get(case.get("act"), 0)
+    if act == 1:
+        ref = F.silu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+
+    pw = ops.pack_conv(w, b, dtype, _dev())
+    split = case.get("split")
+    if split and split % per:
+        pytest.skip("split not aligned for this dtype")
+    x0 = _nhwc(x[:, :split] if split else x, dtype)
+    x1 = _nhwc(x[:, split:], dtype) if split else None
+    out_hw = (ref.shape[2], ref.shape[3])
+    got = ops.conv2d(x0, pw, x1=x1, stride=stride, pad=(pad, pad), out_hw=out_hw, upsample2x=bool(case.get("ups")),
+                     emb=None if emb is None else emb.to(_dev())[:, :], res=None if res is None else _nhwc(res, dtype),
+                     out_scale=case.get("scale", 1.0), act=act, out_nchw_f32=bool(case.get("nchw")))
+    torch.cuda.synchronize()
+    if not case.get("nchw"):
+        got = got.permute(0, 3, 1, 2)
+    _close(got, ref, _tol(dtype), "conv2d")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_linear(dtype):
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(5, 256, generator=g)
+    w = torch.randn(192, 256, generator=g) / 16
+    b = torch.randn(192, generator=g)
+    pw = ops.pack_conv(w, b, dtype, _dev())
+    got = ops.conv2d(x.to(_dev(), dtype), pw, act=1)
+    ref = F.silu(F.linear(_rt(x, dtype), _rt(w, dtype), b))
+    _close(got, ref, _tol(dtype), "linear")
+
+
+GN_CASES = [
+    dict(B=2, C=64, HW=64, G=32),
+    dict(B=2, C=256, HW=1024, G=32, silu=True),
+    dict(B=1, C=768, HW=256, G=32, silu=True),               # 96 chunks per pixel (not a power of two)
+    dict(B=3, C=64, HW=1, G=32),                             # single pixel
+    dict(B=2, C=64, HW=36, G=4, split=40, silu=True),        # group 2 straddles the concat boundary
+    dict(B=2, C=128, HW=64, G=32, film=True, silu=True),     # scale/shift (unet_adm.py:248-252)
+    dict(B=2, C=32, HW=16, G=8, eps=1e-6),                   # EDM groups=min(32,C/4) (edm_networks.py:108)
+    dict(B=1, C=2048, HW=64, G=32, silu=True),               # widest ADM-256 concat
+    dict(B=1, C=256, HW=65536, G=32, silu=True),             # ADM-256 full-resolution map, 64 stat blocks
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", GN_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_groupnorm(case, dtype):
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, Cc, HW, G = case["B"], case["C"], case["HW"], case["G"]
+    eps = case.get("eps", 1e-5)
+    x = torch.randn(B, Cc, HW, generator=g) * 1.7 + 0.3
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    beta = 0.1 * torch.randn(Cc, generator=g)
+    xr = _rt(x, dtype)
+    ref = F.group_norm(xr, G, gamma, beta, eps)
+    scale = shift = None
+    if case.get("film"):
+        ss = torch.randn(B, 2 * Cc, generator=g) * 0.3
+        scale, shift = ss[:, :Cc], ss[:, Cc:]
+        ref = ref * (1 + scale[:, :, None]) + shift[:, :, None]
+        ss_d = ss.to(_dev())
+        scale, shift = ss_d[:, :Cc], ss_d[:, Cc:]
+    if case.get("silu"):
+        ref = F.silu(ref)
+    xd = x.permute(0, 2, 1).contiguous().to(_dev(), dtype)
+    split = case.get("split")
+    x0 = xd[..., :split].contiguous() if split else xd
+    x1 = xd[..., split:].contiguous() if split else None
+    got = ops.groupnorm(x0, gamma.to(_dev()), beta.to(_dev()), groups=G, eps=eps, silu=bool(case.get("silu")),
+                        x1=x1, scale=scale, shift=shift)
+    _close(got.permute(0, 2, 1), ref, _tol(dtype) * (1 if dtype == torch.float32 else 1.5), "groupnorm")
+
+
+ATTN_CASES = [
+    dict(B=2, T=64, H=2, D=32), dict(B=1, T=256, H=4, D=64), dict(B=2, T=100, H=1, D=64),
+    dict(B=2, T=4, H=2, D=64), dict(B=1, T=1024, H=2, D=64), dict(B=1, T=80, H=1, D=128),
+    dict(B=1, T=48, H=1, D=256), dict(B=1, T=70, H=1, D=512),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_attention(case, dtype):
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, H, D = case["B"], case["T"], case["H"], case["D"]
+    qkv = torch.randn(B, T, 3, H, D, generator=g)
+    qkv[:, :, :2] *= D ** -0.25 * 1.5          # realistic logit scale after the folded ch^-1/4
+    r = _rt(qkv, dtype)
+    q, k, v = r[:, :, 0], r[:, :, 1], r[:, :, 2]          # [B,T,H,D]
+    s = torch.einsum("bthd,bshd->bhts", q, k)
+    p = torch.softmax(s, dim=-1)
+    ref = torch.einsum("bhts,bshd->bthd", p, v).reshape(B, T, H * D)
+    got = ops.attention(qkv.reshape(B, T, 3 * H * D).to(_dev(), dtype), H)
+    _close(got, ref, _tol(dtype) * (1 if dtype == torch.float32 else 1.5), "attention")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_resample_and_layout(dtype):
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 6, 10, generator=g)
+    xr = _rt(x, dtype)
+    xd = _nhwc(x, dtype)
+    _close(ops.avgpool2x2(xd).permute(0, 3, 1, 2), F.avg_pool2d(xr, 2), _tol(dtype), "avgpool")
+    _close(ops.upsample2x(xd).permute(0, 3, 1, 2), F.interpolate(xr, scale_factor=2, mode="nearest"), 1e-7, "upsample")
+    _close(ops.pad_rb(xd).permute(0, 3, 1, 2), F.pad(xr, (0, 1, 0, 1)), 1e-7, "pad_rb")
+    _close(ops.nhwc_to_nchw_f32(xd), xr, 1e-7, "nhwc->nchw")
+    back = ops.nchw_f32_to_nhwc(x.to(_dev()), dtype)
+    _close(back.permute(0, 3, 1, 2), xr, 1e-7, "nchw->nhwc")
+    # odd, non-multiple-of-32 sizes through the transpose tiles
+    y = torch.randn(3, 40, 5, 7, generator=g)
+    _close(ops.nhwc_to_nchw_f32(_nhwc(y, dtype)), _rt(y, dtype), 1e-7, "nhwc->nchw ragged")
+
+
+def test_timestep_embedding():
+    from diffusion_nlc_amd import ops
+    t = torch.tensor([0.0, 1.0, 17.5, 954.0, 1000.0])
+    half = 64
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    got = ops.timestep_embedding(t.to(_dev()), freqs.to(_dev()), sin_first=False)
+    assert (got.cpu() - ref).abs().max().item() < 2e-6
+    got = ops.timestep_embedding(t.to(_dev()), freqs.to(_dev()), sin_first=True)
+    assert (got.cpu() - torch.cat([torch.sin(args), torch.cos(args)], dim=-1)).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_conv_first(dtype):
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 20, 33, generator=g)
+    w = torch.randn(40, 3, 3, 3, generator=g) / 5
+    b = torch.randn(40, generator=g) * 0.1
+    sc = torch.tensor([0.5, 1.25])
+    ref = F.conv2d(x * sc[:, None, None, None], w, b, padding=1)
+    wp = w.permute(0, 2, 3, 1).reshape(40, 9, 3).contiguous().to(_dev())
+    got = ops.conv_first(x.to(_dev()), wp, b.to(_dev()), dtype, in_scale=sc.to(_dev()))
+    _close(got.permute(0, 3, 1, 2), ref, 1e-5 if dtype == torch.float32 else 1e-2, "conv_first")
+
+
+def test_row_sumsq_and_quantile():
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 6, 17, 19, generator=g)
+    ss = ops.row_sumsq(x.to(_dev())).cpu()
+    ref = (x.reshape(3, -1) ** 2).sum(1)
+    assert ((ss - ref).abs() / ref).max().item() < 1e-5
+    ss3 = ops.row_sumsq(x.to(_dev()), d_used=3 * 17 * 19).cpu()
+    ref3 = (x[:, :3].reshape(3, -1) ** 2).sum(1)
+    assert ((ss3 - ref3).abs() / ref3).max().item() < 1e-5
+    # exact order statistics: must equal torch.quantile bit for bit before the clamp
+    for shape, q in (((4, 3, 32, 32), 0.99), ((2, 3, 64, 64), 0.99), ((3, 1, 5, 5), 0.5), ((2, 3, 256, 256), 0.99)):
+        y = torch.randn(*shape, generator=g) * 2.5
+        y[0].mul_(0.2)                                   # below the clamp floor of 1
+        ref = torch.quantile(y.reshape(shape[0], -1).abs(), q, dim=1).clamp(min=1, max=100)
+        got = ops.dynamic_threshold(y.to(_dev()), q, 100.0).cpu()
+        assert torch.equal(got, ref), (shape, got, ref)
+    # ties everywhere
+    z = torch.ones(2, 3, 8, 8) * 3.0
+    assert torch.equal(ops.dynamic_threshold(z.to(_dev()), 0.99, 100.0).cpu(), torch.tensor([3.0, 3.0]))
