@@ -3,8 +3,8 @@
 // HBM-bound: 2 reads + 1 write of the activation.  Two launches:
 //   1. gn_stats:  grid (NBLK, B).  Each workgroup streams a contiguous pixel range of one
 //      image with fully coalesced 16-byte loads (a pixel's channels are contiguous), keeps
-//      per-thread f32 sum / sum-of-squares for a FIXED set of channels, reduces them in LDS in
-//      a fixed order (deterministic - no atomics) to per-group partials -> workspace.
+//      per-thread f32 shifted sums for a FIXED set of channels, merges them in LDS in a fixed
+//      order (deterministic - no atomics) into per-group (count, mean, M2) partials -> workspace.
 //   2. gn_apply:  grid (NBLK2, B).  Each workgroup folds the partials (f64) into
 //      a[c] = rstd*gamma*(1+scale), b[c] = (beta-mean*rstd*gamma)*(1+scale)+shift  in LDS, then
 //      streams  y = act(a[c]*x + b[c])  with 16-byte loads/stores.
@@ -33,7 +33,7 @@ struct GNParams {
     const float* scale; const float* shift; int ss_stride;
     int silu;
     char* out;
-    float* ws;          // [B][nblk][G][2]
+    double* ws;         // [B][nblk][G][3] = (count, mean, M2)
 };
 
 template <typename T>
@@ -46,11 +46,14 @@ __device__ __forceinline__ uint4 load_chunk(const GNParams& p, int b, int64_t pi
     return *reinterpret_cast<const uint4*>(ptr);
 }
 
+// Statistics are carried as (count, mean, M2) triples and merged with Chan's formula in f64;
+// each thread accumulates sums of (x - x_first) so that E[x^2]-E[x]^2 cancellation never
+// appears even for two-element groups with |mean| >> std.
 template <typename T>
 __global__ __launch_bounds__(NT) void gn_stats_kernel(const GNParams p) {
     constexpr int PER = ElemTraits<T>::kPerChunk;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);   // [ps][C][2]
+    float* red = reinterpret_cast<float*>(smem);   // [ps][C][3] = (n, mean, M2)
 
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const int active = p.tpp * p.ps;
@@ -58,14 +61,15 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const GNParams p) {
     const int pix0 = blk * p.pix_per_blk;
     const int pix1 = min(pix0 + p.pix_per_blk, p.HW);
 
-    float s[MAX_SLOTS][PER], q[MAX_SLOTS][PER];
+    float s[MAX_SLOTS][PER], q[MAX_SLOTS][PER], x0[MAX_SLOTS][PER];
 #pragma unroll
     for (int k = 0; k < MAX_SLOTS; ++k)
 #pragma unroll
-        for (int j = 0; j < PER; ++j) { s[k][j] = 0.f; q[k][j] = 0.f; }
+        for (int j = 0; j < PER; ++j) { s[k][j] = 0.f; q[k][j] = 0.f; x0[k][j] = 0.f; }
+    int cnt = 0;
 
     if (tid < active) {
-        for (int pix = pix0 + pl; pix < pix1; pix += p.ps) {
+        for (int pix = pix0 + pl; pix < pix1; pix += p.ps, ++cnt) {
 #pragma unroll
             for (int k = 0; k < MAX_SLOTS; ++k) {
                 const int chunk = tx + k * p.tpp;
@@ -73,10 +77,15 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const GNParams p) {
                     float f[PER];
                     chunk_to_f32<T>(load_chunk<T>(p, b, pix, chunk), f);
 #pragma unroll
-                    for (int j = 0; j < PER; ++j) { s[k][j] += f[j]; q[k][j] += f[j] * f[j]; }
+                    for (int j = 0; j < PER; ++j) {
+                        if (cnt == 0) x0[k][j] = f[j];
+                        const float d = f[j] - x0[k][j];
+                        s[k][j] += d; q[k][j] += d * d;
+                    }
                 }
             }
         }
+        const float n = (float)cnt;
 #pragma unroll
         for (int k = 0; k < MAX_SLOTS; ++k) {
             const int chunk = tx + k * p.tpp;
@@ -84,22 +93,33 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const GNParams p) {
 #pragma unroll
                 for (int j = 0; j < PER; ++j) {
                     const int c = chunk * PER + j;
-                    red[((int64_t)pl * p.C + c) * 2 + 0] = s[k][j];
-                    red[((int64_t)pl * p.C + c) * 2 + 1] = q[k][j];
+                    float* r = red + ((int64_t)pl * p.C + c) * 3;
+                    const float ms = cnt ? s[k][j] / n : 0.f;
+                    r[0] = n;
+                    r[1] = x0[k][j] + ms;
+                    r[2] = cnt ? fmaxf(q[k][j] - s[k][j] * ms, 0.f) : 0.f;
                 }
             }
         }
     }
     __syncthreads();
     for (int g = tid; g < p.G; g += NT) {
-        float ss = 0.f, qq = 0.f;
+        double N = 0.0, sm = 0.0;
         for (int l = 0; l < p.ps; ++l)
             for (int c = g * p.gs; c < (g + 1) * p.gs; ++c) {
-                ss += red[((int64_t)l * p.C + c) * 2 + 0];
-                qq += red[((int64_t)l * p.C + c) * 2 + 1];
+                const float* r = red + ((int64_t)l * p.C + c) * 3;
+                N += (double)r[0]; sm += (double)r[0] * (double)r[1];
             }
-        float* w = p.ws + (((int64_t)b * p.nblk + blk) * p.G + g) * 2;
-        w[0] = ss; w[1] = qq;
+        const double mean = N > 0.0 ? sm / N : 0.0;
+        double m2 = 0.0;
+        for (int l = 0; l < p.ps; ++l)
+            for (int c = g * p.gs; c < (g + 1) * p.gs; ++c) {
+                const float* r = red + ((int64_t)l * p.C + c) * 3;
+                const double dm = (double)r[1] - mean;
+                m2 += (double)r[2] + (double)r[0] * dm * dm;
+            }
+        double* w = p.ws + (((int64_t)b * p.nblk + blk) * p.G + g) * 3;
+        w[0] = N; w[1] = mean; w[2] = m2;
     }
 }
 
@@ -114,13 +134,17 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const GNParams p) {
 
     const int b = blockIdx.y, tid = threadIdx.x;
     for (int g = tid; g < p.G; g += NT) {
-        double ss = 0.0, qq = 0.0;
-        const float* w = p.ws + ((int64_t)b * p.nblk * p.G + g) * 2;
-        for (int k = 0; k < p.nblk; ++k) { ss += (double)w[(int64_t)k * p.G * 2]; qq += (double)w[(int64_t)k * p.G * 2 + 1]; }
-        const double n = (double)p.HW * p.gs;
-        const double mean = ss / n;
-        double var = qq / n - mean * mean;
-        if (var < 0.0) var = 0.0;
+        const double* w = p.ws + ((int64_t)b * p.nblk * p.G + g) * 3;
+        double N = 0.0, sm = 0.0;
+        for (int k = 0; k < p.nblk; ++k) { const double* r = w + (int64_t)k * p.G * 3; N += r[0]; sm += r[0] * r[1]; }
+        const double mean = sm / N;
+        double m2 = 0.0;
+        for (int k = 0; k < p.nblk; ++k) {
+            const double* r = w + (int64_t)k * p.G * 3;
+            const double dm = r[1] - mean;
+            m2 += r[2] + r[0] * dm * dm;
+        }
+        const double var = m2 / N;
         gm[g] = (float)mean;
         gr[g] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
@@ -178,7 +202,7 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
 
 extern "C" int64_t nlc_groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
     (void)HW; (void)C;
-    return (int64_t)B * MAX_NBLK * groups * 2 * sizeof(float);
+    return (int64_t)B * MAX_NBLK * groups * 3 * sizeof(double);
 }
 
 extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, float eps,
@@ -198,8 +222,8 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
     GNParams p;
     fill_params(p, x0, x1, C0, C1, B, HW, groups, dtype);
     p.eps = eps; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
-    p.silu = silu; p.out = (char*)out; p.ws = (float*)workspace;
-    const size_t lds_stats = (size_t)p.ps * p.C * 2 * sizeof(float);
+    p.silu = silu; p.out = (char*)out; p.ws = (double*)workspace;
+    const size_t lds_stats = (size_t)p.ps * p.C * 3 * sizeof(float);
     const size_t lds_apply = ((size_t)2 * p.C + 2 * p.G) * sizeof(float);
     NLC_REQUIRE(lds_stats <= 64 * 1024 && lds_apply <= 64 * 1024, "nlc_groupnorm: LDS budget exceeded (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;

@@ -202,9 +202,13 @@ def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
     out = torch.empty(*x0.shape[:-1], Ctot, device=x0.device, dtype=dt)
     ss_stride = 0
     if scale is not None:
-        _need(scale, torch.float32, "groupnorm scale")
+        # scale / shift are usually the two halves of one [B, 2C] embedding row: row-strided views
+        for nm, v in (("scale", scale), ("shift", shift)):
+            if v is None or v.dtype != torch.float32 or not v.is_cuda or v.dim() != 2 or v.stride(1) != 1 \
+                    or v.shape[1] < Ctot:
+                raise ValueError(f"groupnorm: {nm} must be a CUDA f32 [B, >=C] view with unit inner stride")
         ss_stride = scale.stride(0)
-        if shift is None or shift.stride(0) != ss_stride:
+        if shift.stride(0) != ss_stride:
             raise ValueError("groupnorm: scale/shift must share a row stride")
     ws = _gn_workspace(x0.device, lib.nlc_groupnorm_workspace_bytes(B, HW, Ctot, groups))
     check(lib.nlc_groupnorm(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
