@@ -41,6 +41,11 @@ def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     return e
 
 
+def _swish(x: torch.Tensor) -> torch.Tensor:
+    """nonlinearity (src/unet_simple.py:27-29): x*sigmoid(x), not F.silu (differs in the last ulp)."""
+    return x * torch.sigmoid(x)
+
+
 def _norm(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     """Normalize: GroupNorm(32, eps=1e-6) (src/unet_simple.py:32-33)."""
     return F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], 1e-6)
@@ -52,10 +57,10 @@ def _conv(sd: SD, p: str, x: torch.Tensor, stride: int = 1, padding: int = 1) ->
 
 def resnet_block(sd: SD, p: str, x: torch.Tensor, temb: Optional[torch.Tensor]) -> torch.Tensor:
     """ResnetBlock.forward (src/unet_simple.py:115-134); temb=None -> PureResnetBlock (:461-478)."""
-    h = _conv(sd, p + ".conv1", F.silu(_norm(sd, p + ".norm1", x)))
+    h = _conv(sd, p + ".conv1", _swish(_norm(sd, p + ".norm1", x)))
     if temb is not None:
-        h = h + F.linear(F.silu(temb), sd[p + ".temb_proj.weight"], sd[p + ".temb_proj.bias"])[:, :, None, None]
-    h = _conv(sd, p + ".conv2", F.silu(_norm(sd, p + ".norm2", h)))
+        h = h + F.linear(_swish(temb), sd[p + ".temb_proj.weight"], sd[p + ".temb_proj.bias"])[:, :, None, None]
+    h = _conv(sd, p + ".conv2", _swish(_norm(sd, p + ".norm2", h)))
     if (p + ".nin_shortcut.weight") in sd:
         x = _conv(sd, p + ".nin_shortcut", x, padding=0)
     elif (p + ".conv_shortcut.weight") in sd:
@@ -90,7 +95,7 @@ def unet(sd: SD, cfg: SimpleConfig, x: torch.Tensor, t: torch.Tensor, mode: str 
     nres = len(cfg.ch_mult)
     temb = timestep_embedding(t, cfg.ch)
     temb = F.linear(temb, sd["temb.dense.0.weight"], sd["temb.dense.0.bias"])
-    temb = F.linear(F.silu(temb), sd["temb.dense.1.weight"], sd["temb.dense.1.bias"])
+    temb = F.linear(_swish(temb), sd["temb.dense.1.weight"], sd["temb.dense.1.bias"])
 
     hs = [_conv(sd, "conv_in", x)]
     res = cfg.resolution
@@ -125,7 +130,7 @@ def unet(sd: SD, cfg: SimpleConfig, x: torch.Tensor, t: torch.Tensor, mode: str 
             if cfg.resamp_with_conv:
                 h = _conv(sd, f"up.{lvl}.upsample.conv", h)
             res *= 2
-    out = _conv(sd, "conv_out", F.silu(_norm(sd, "norm_out", h)))
+    out = _conv(sd, "conv_out", _swish(_norm(sd, "norm_out", h)))
     return out if mode == "forward" else (out, feat)
 
 

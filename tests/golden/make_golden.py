@@ -1,0 +1,282 @@
+"""Generate the golden fixtures in tests/golden/ by importing the REFERENCE (read-only at
+/root/reference) in the build container.  Never runs on the GPU box (the reference does not
+travel); the .npz / .json files it writes are committed and are the only thing tests read.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Every fixture records torch.__version__ and the thread count.  Weights come from
+diffusion_nlc_amd.filler (the same rule the product and the oracle use), applied to the
+reference module's own state_dict, so key names/shapes are the reference's.
+"""
+from __future__ import annotations
+
+import argparse
+import itertools
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+REF = Path("/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(REF))
+
+from diffusion_nlc_amd.filler import checksum, fill_state_dict  # noqa: E402
+
+
+def _stub_missing_modules():
+    """Peripheral packages the reference imports but that are not installed here."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    mod("more_itertools", pairwise=itertools.pairwise)
+    mod("pytorch_fid")
+    mod("pytorch_fid.fid_score", compute_statistics_of_path=None, calculate_frechet_distance=None, calculate_fid_given_paths=None)
+
+    class _Inc:
+        BLOCK_INDEX_BY_DIM = {2048: 3}
+    mod("pytorch_fid.inception", InceptionV3=_Inc)
+    tv = mod("torchvision")
+    tv.utils = mod("torchvision.utils", save_image=lambda *a, **k: None)
+    mod("cv2")
+
+
+META = dict(torch=torch.__version__, threads=torch.get_num_threads())
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(HERE / f"{name}.npz", _meta=json.dumps(META), **out)
+    print("wrote", name, {k: tuple(np.shape(v)) for k, v in out.items()})
+
+
+def spec_of(module):
+    return {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in module.state_dict().items()}
+
+
+# ---------------------------------------------------------------------------------------
+ADM_TINY = dict(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2,4", learn_sigma=True,
+                attention_resolutions="16,8", num_heads=1, num_head_channels=32, use_scale_shift_norm=True,
+                resblock_updown=True, use_new_attention_order=False, sigma_block=2)
+ADM_TINY_B = dict(image_size=32, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", learn_sigma=False,
+                  attention_resolutions="16", num_heads=2, num_head_channels=-1, use_scale_shift_norm=False,
+                  resblock_updown=False, use_new_attention_order=True, sigma_block=2)
+SIMPLE_TINY = dict(ch=64, out_ch=3, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[16], dropout=0.0,
+                   in_channels=3, resamp_with_conv=True, feat_layer=1, sigma_block=2, sigma_dropout=0.0, type="simple",
+                   image_size=32, num_diffusion_timesteps=1000)
+EDM_TINY = dict(img_resolution=32, in_channels=3, out_channels=3, augment_dim=9, model_channels=32, channel_mult=[2, 2, 2],
+                num_blocks=2, attn_resolutions=[16], dropout=0.0, sigma_block=2)
+SIGMA_OVERRIDES = {"final_mlp.weight": 0.1, "final_mlp.bias": 0.5}
+
+
+def simple_namespace(c):
+    ns = argparse.Namespace
+    return ns(model=ns(ch=c["ch"], out_ch=c["out_ch"], ch_mult=c["ch_mult"], num_res_blocks=c["num_res_blocks"],
+                       attn_resolutions=c["attn_resolutions"], dropout=c["dropout"], in_channels=c["in_channels"],
+                       resamp_with_conv=c["resamp_with_conv"], feat_layer=c["feat_layer"], type=c["type"],
+                       sigma_block=c["sigma_block"], sigma_dropout=c["sigma_dropout"]),
+              data=ns(image_size=c["image_size"]), diffusion=ns(num_diffusion_timesteps=c["num_diffusion_timesteps"]))
+
+
+def build_models():
+    from src import script_util
+    models = {}
+    for tag, kw in (("adm_tiny", ADM_TINY), ("adm_tiny_b", ADM_TINY_B)):
+        eps, sig, fshape = script_util.create_sigma_eps_model(**kw)
+        models[tag] = (eps, sig, fshape)
+    eps, sig, fshape = script_util.create_simple_sigma_eps_model(simple_namespace(SIMPLE_TINY))
+    models["simple_tiny"] = (eps, sig, fshape)
+    eps, sig, fshape = script_util.create_edm_sigma_eps_model(**EDM_TINY)
+    models["edm_tiny"] = (eps, sig, fshape)
+    for tag, (eps, sig, _) in models.items():
+        eps.load_state_dict(fill_state_dict(eps.state_dict(), seed=0))
+        sig.load_state_dict(fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES))
+        eps.eval(); sig.eval()
+    return models
+
+
+def gen_specs(models):
+    specs = {}
+    for tag, (eps, sig, fshape) in models.items():
+        specs[tag] = dict(eps=spec_of(eps), sigma=spec_of(sig), feat_shape=list(fshape),
+                          eps_checksum=checksum(eps.state_dict()), sigma_checksum=checksum(sig.state_dict()))
+    specs["_configs"] = dict(adm_tiny=ADM_TINY, adm_tiny_b=ADM_TINY_B, simple_tiny=SIMPLE_TINY, edm_tiny=EDM_TINY,
+                             sigma_overrides=SIGMA_OVERRIDES)
+    specs["_meta"] = META
+    (HERE / "specs.json").write_text(json.dumps(specs, indent=0))
+    print("wrote specs.json")
+
+
+@torch.no_grad()
+def gen_nets(models):
+    g = torch.Generator().manual_seed(100)
+    for tag, (eps, sig, fshape) in models.items():
+        res = 64 if tag == "adm_tiny" else 32
+        x = torch.randn(2, 3, res, res, generator=g)
+        if tag.startswith("edm"):
+            t = torch.tensor([-1.3, 0.9])                      # c_noise = ln(sigma)/4
+            out = eps(x, t, None)
+            feat = eps.encode(x, t, None)
+            save(f"net_{tag}", x=x, t=t, out=out, feat=feat, r=sig(feat))
+        else:
+            t = torch.tensor([17.5, 1000.0])                   # fractional and the clamp ceiling
+            out = eps(x, t)
+            feat = eps.encode(x, t)
+            out2, feat2 = eps.forward_and_encode(x, t)
+            assert torch.equal(out, out2) and torch.equal(feat, feat2)
+            save(f"net_{tag}", x=x, t=t, out=out, feat=feat, r=sig(feat))
+
+
+def gen_sched():
+    from src.schedulers import get_sampler
+    arrays = {}
+    for steps in (10, 50, 100):
+        s = get_sampler("ddim", 1000, steps, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall")
+        arrays[f"timesteps_{steps}"] = s.timesteps
+        arrays[f"sampling_sigmas_{steps}"] = s.sampling_sigmas
+        arrays[f"min_var_coef_{steps}"] = s.min_var_coef
+    arrays["sigmas"] = s.sigmas
+    arrays["alphas_cumprod"] = s.alphas_cumprod
+    grid = torch.cat([torch.tensor([0.0, 0.005, 0.0100008, 1.0, 157.0, 157.5, 1e4]), s.sigmas[[0, 1, 500, 998, 999]],
+                      torch.logspace(-2.2, 2.3, 40)])
+    arrays["t_grid_sigma"] = grid
+    arrays["t_grid_t"] = s.get_t_from_sigma(grid)
+    for sched in ("quadratic", "cosine", "sigmoid"):
+        s2 = get_sampler("ddim", 1000, 20, beta_schedule=sched, sigma_style="DDIM", start_sigma=0, end_sigma=0)
+        arrays[f"sigmas_{sched}"] = s2.sigmas
+        arrays[f"timesteps_{sched}"] = s2.timesteps
+    s3 = get_sampler("ddim", 1000, 10, sigma_style="DDIM", start_sigma=100, end_sigma=0, set_alpha_to_one=False)
+    arrays["timesteps_noalpha1"] = s3.timesteps
+    arrays["sampling_sigmas_noalpha1"] = s3.sampling_sigmas
+    # log-variance + pred_xprev for every sampler / var mode, per-sample sigmas
+    g = torch.Generator().manual_seed(5)
+    B = 3
+    x0 = torch.randn(B, 3, 8, 8, generator=g)
+    xt = x0 + 2.0 * torch.randn(B, 3, 8, 8, generator=g)
+    eps = torch.randn(B, 3, 8, 8, generator=g)
+    learned = torch.rand(B, 3, 8, 8, generator=g) * 2 - 1
+    noise = torch.randn(B, 3, 8, 8, generator=g)
+    st = torch.tensor([3.0, 0.7, 0.05]).view(B, 1, 1, 1)
+    sp = torch.tensor([2.2, 0.4, 0.0]).view(B, 1, 1, 1)
+    arrays.update(px_x0=x0, px_xt=xt, px_eps=eps, px_learned=learned, px_noise=noise, px_st=st, px_sp=sp)
+    import src.schedulers as RS
+    orig_randn_like = torch.randn_like
+    for name in ("ddpm", "ddim", "ddim_simple", "ddim_orig", "ddim_simple_orig", "ddim_simple_drag", "ddpm_orig"):
+        for var in ("fixedsmall", "fixedlarge", "learned"):
+            for eta in (0.0, 0.85):
+                s = get_sampler(name, 1000, 50, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var=var, eta=eta)
+                lv = s.get_eps_logvar(st, sp, learned if var == "learned" else None)
+                RS.torch.randn_like = lambda t: noise          # host-ordered noise injection
+                try:
+                    xp = s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=xt, log_variance=lv)
+                finally:
+                    RS.torch.randn_like = orig_randn_like
+                arrays[f"px_{name}_{var}_{eta}"] = xp
+                arrays[f"lv_{var}"] = lv
+    save("sched", **arrays)
+
+
+class _RefNoise:
+    """Replays a recorded list of per-step noise tensors through torch.randn_like."""
+    def __init__(self, gen):
+        self.gen = gen
+        self.drawn = []
+
+    def __call__(self, t):
+        z = torch.randn(t.shape, generator=self.gen, dtype=t.dtype)
+        self.drawn.append(z)
+        return z
+
+
+@torch.no_grad()
+def gen_loops(models):
+    from src.schedulers import get_sampler
+    from src.experiments import ImageExperiment, EDMImageExperiment
+    import src.schedulers as RS
+
+    def run(tag, res, *, steps, sampler="ddim", var="fixedsmall", eta=0.0, style="pred", norm_eps=True, refine=True,
+            clip="clamp", norm_max=54.63, norm_min=0.0, threshold=960, start_sigma=100, B=2, seed=1234, name=None):
+        eps, sig, _ = models[tag]
+        learn = tag == "adm_tiny"
+        sch = get_sampler(sampler, 1000, steps, sigma_style="DDIM", start_sigma=start_sigma, end_sigma=0, sampler_var=var, eta=eta)
+        exp = ImageExperiment(eps, sch, batch_size=B, data_shape=(3, res, res), seed=seed, device="cpu", save_folder="/tmp")
+        exp.set_model(eps, sig, learn_epsvar=learn)
+        exp.set_norm_maxmin(norm_min, norm_max)
+        exp.set_clip_fn(clip)
+        gen = exp.new_gen()
+        z = torch.randn((B, 3, res, res), generator=gen)       # what get_noise will draw next from the same seed
+        gen = exp.new_gen()
+        rec = _RefNoise(torch.Generator().manual_seed(seed + 1))
+        orig = torch.randn_like
+        RS.torch.randn_like = rec
+        try:
+            x, logs = exp.denoise_loop(shape=(B, 3, res, res), gen=gen, style=style, norm_eps=norm_eps,
+                                       refine_prior_sigma=refine, return_log=True, chunk_size=1,
+                                       sigma_pred_threshold=threshold)
+        finally:
+            RS.torch.randn_like = orig
+        x0s, epss = torch.stack(logs[3]), torch.stack(logs[1])
+        # fixtures stay small: the full first-step x0 plus per-step per-sample (mean, mean|.|) traces,
+        # which move visibly if a searchsorted flip changes a timestep.  Step noise (eta > 0) is
+        # regenerated in the tests from torch.Generator().manual_seed(seed + 1), same draw order.
+        stats = lambda a: torch.stack([a.flatten(2).mean(-1), a.flatten(2).abs().mean(-1)], dim=-1)
+        arrays = dict(z=z, x=x, x0_first=x0s[0], x0_stats=stats(x0s), eps_stats=stats(epss), n_noise=len(rec.drawn))
+        cfg = dict(tag=tag, res=res, steps=steps, sampler=sampler, var=var, eta=eta, style=style, norm_eps=norm_eps,
+                   refine=refine, clip=clip, norm_max=norm_max, norm_min=norm_min, threshold=threshold,
+                   start_sigma=start_sigma, B=B, seed=seed)
+        save(name, cfg=json.dumps(cfg), **arrays)
+
+    # BASELINE config 1: unet_simple 32x32, 10-step DDIM + NLC
+    run("simple_tiny", 32, steps=10, B=4, name="loop_simple_pred")
+    run("simple_tiny", 32, steps=10, style="base", norm_eps=False, refine=False, name="loop_simple_base")
+    run("simple_tiny", 32, steps=10, style="pred_partial", name="loop_simple_partial")
+    run("simple_tiny", 32, steps=10, sampler="ddim_simple_orig", eta=0.85, name="loop_simple_orig_eta")
+    run("simple_tiny", 32, steps=12, start_sigma=150, threshold=900, name="loop_simple_threshold")   # crosses sigma_pred_threshold
+    # ADM: learned variance + dynamic clip (imagenet preset, image_sample.py:153-161), and eta>0 DDIM
+    run("adm_tiny", 64, steps=10, var="learned", clip="dynamic", norm_max=440.0 * 64 / 256, name="loop_adm_dynamic")
+    run("adm_tiny", 64, steps=8, var="learned", eta=0.85, clip="dynamic", norm_max=110.0, name="loop_adm_eta")
+    run("adm_tiny_b", 32, steps=8, sampler="ddpm", var="fixedlarge", clip="none", name="loop_admb_ddpm")
+
+    # EDM / Heun + NLC (BASELINE config 3, reduced)
+    eps, sig, _ = models["edm_tiny"]
+    for name, style, second, norm in (("loop_edm_pred", "pred_partial,pred", True, "00"), ("loop_edm_base", "base,base", True, "00"),
+                                      ("loop_edm_euler", "pred,pred", False, "10")):
+        exp = EDMImageExperiment(eps, None, batch_size=2, data_shape=(3, 32, 32), seed=0, device="cpu", save_folder="/tmp",
+                                 num_timesteps=6)
+        exp.set_model(eps, sig, learn_epsvar=False)
+        exp.set_norm_maxmin(0.0, 54.63)
+        lat = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(77))
+
+        class G:
+            def randn(self, shape, device=None):
+                return lat
+        torch.manual_seed(3)
+        x = exp.edm_sampler(shape=(2, 3, 32, 32), gen=G(), style=style, norm_eps=norm + "0", refine_prior_sigma=False,
+                            eps_ratio=0.5, eps_scale=1.0, use_second_order=second)
+        save(name, latents=lat, x=x, cfg=json.dumps(dict(style=style, second=second, norm_eps=norm + "0", steps=6)))
+
+
+def main():
+    _stub_missing_modules()
+    torch.manual_seed(0)
+    models = build_models()
+    gen_specs(models)
+    gen_nets(models)
+    gen_sched()
+    gen_loops(models)
+
+
+if __name__ == "__main__":
+    main()
