@@ -1,0 +1,259 @@
+"""Common machinery of the HIP-backed networks: reference-format parameters on the host,
+packed weights on the device, and the building blocks shared by the three UNet families.
+
+A ``HipModule`` looks like the ``nn.Module`` it replaces to the reference's entry points
+(``state_dict`` / ``load_state_dict`` with the reference's key names, ``parameters``, ``to``,
+``eval``, ``convert_to_fp16``) but owns no autograd state: parameters are plain f32 host tensors
+that are packed once per (device, compute dtype) into the layouts the kernels want.
+
+Compute dtype: ``torch.float32`` (exact f32 MFMA, the parity path) or ``torch.bfloat16``
+(bf16 operands / f32 accumulate, the throughput path).  The reference's ``convert_to_fp16``
+maps to bf16 here: like the reference's fp16 mode it touches convolution operands only -
+GroupNorm statistics, softmax, timestep-embedding MLPs and the sigma head stay f32
+(src/fp16_util.py:15-22, src/unet_adm.py:620-626,1060-1065).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._ext import ACT_GELU, ACT_NONE, ACT_SILU, NlcError
+
+
+class SpecBuilder:
+    """Collects (key -> shape) in module-construction order, mirroring nn.Module.state_dict()."""
+
+    def __init__(self):
+        self.spec: "OrderedDict[str, Tuple[Tuple[int, ...], torch.dtype]]" = OrderedDict()
+
+    def add(self, key, shape, dtype=torch.float32):
+        self.spec[key] = (tuple(int(s) for s in shape), dtype)
+
+    def conv(self, p, cout, cin, k, bias=True, dims=2):
+        self.add(p + ".weight", (cout, cin) + (k,) * dims)
+        if bias:
+            self.add(p + ".bias", (cout,))
+
+    def linear(self, p, cout, cin, bias=True):
+        self.add(p + ".weight", (cout, cin))
+        if bias:
+            self.add(p + ".bias", (cout,))
+
+    def norm(self, p, c):
+        self.add(p + ".weight", (c,))
+        self.add(p + ".bias", (c,))
+
+    def batchnorm(self, p, c):
+        self.norm(p, c)
+        self.add(p + ".running_mean", (c,))
+        self.add(p + ".running_var", (c,))
+        self.add(p + ".num_batches_tracked", (), torch.int64)
+
+
+class HipModule:
+    """Parameter container + lazy device plan.  Subclasses implement ``param_spec`` and ``_build``."""
+
+    def __init__(self):
+        self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for k, (shape, dt) in self.param_spec().items():
+            self._sd[k] = torch.zeros(shape, dtype=dt)
+        self.device = torch.device("cpu")
+        self.compute_dtype = torch.float32
+        self._plan = None
+        self.training = False
+
+    # ---- nn.Module look-alike surface ---------------------------------------------------
+    def param_spec(self):
+        raise NotImplementedError
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._sd.items())
+
+    def load_state_dict(self, sd, strict: bool = True):
+        missing = [k for k in self._sd if k not in sd]
+        unexpected = [k for k in sd if k not in self._sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing keys {missing[:8]}"
+                               f"{'...' if len(missing) > 8 else ''}, unexpected keys {unexpected[:8]}")
+        for k, v in sd.items():
+            if k not in self._sd:
+                continue
+            if tuple(v.shape) != tuple(self._sd[k].shape):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(self._sd[k].shape)}")
+            self._sd[k] = v.detach().to("cpu", self._sd[k].dtype).clone()
+        self._plan = None
+        return self
+
+    def parameters(self):
+        return (v for k, v in self._sd.items() if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var", "resample_filter")))
+
+    def buffers(self):
+        return (v for k, v in self._sd.items() if not v.dtype.is_floating_point or k.endswith(("running_mean", "running_var", "resample_filter")))
+
+    def named_parameters(self):
+        return ((k, v) for k, v in self._sd.items() if v.dtype.is_floating_point)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NlcError("the HIP path is inference-only (sigma-net training is out of scope, SURVEY.md §8)")
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            device = torch.device(device)
+            if device.type == "cuda" and device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            if device != self.device:
+                self.device = device
+                self._plan = None
+        if dtype is not None:
+            self.set_compute_dtype(dtype)
+        return self
+
+    def cuda(self, index=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if index is None else index))
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        if dtype == torch.float16:
+            dtype = torch.bfloat16
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("compute dtype must be float32 or bfloat16")
+        if dtype != self.compute_dtype:
+            self.compute_dtype = dtype
+            self._plan = None
+        return self
+
+    def convert_to_fp16(self):
+        """The reference's half-precision switch; on MI355X the low-precision operand type is bf16."""
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def convert_to_fp32(self):
+        return self.set_compute_dtype(torch.float32)
+
+    def bfloat16(self):
+        return self.set_compute_dtype(torch.bfloat16)
+
+    def float(self):
+        return self.set_compute_dtype(torch.float32)
+
+    # ---- plan ---------------------------------------------------------------------------
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise NlcError(f"{type(self).__name__} runs on the HIP kernels only: move it to a GPU with .to('cuda:0') "
+                           "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
+
+    def plan(self):
+        if self._plan is None:
+            self._require_gpu()
+            with torch.cuda.device(self.device):
+                self._plan = self._build(self._sd, self.device, self.compute_dtype)
+        return self._plan
+
+    def _build(self, sd, device, dtype):
+        raise NotImplementedError
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+
+# ------------------------------------------------------------------------------------------
+# building blocks on packed weights
+# ------------------------------------------------------------------------------------------
+def f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Norm:
+    """GroupNorm affine parameters on the device."""
+
+    def __init__(self, sd, p, device, groups: int, eps: float):
+        self.gamma, self.beta = f32(sd[p + ".weight"], device), f32(sd[p + ".bias"], device)
+        self.groups, self.eps = groups, eps
+
+    def __call__(self, x, silu: bool, x1=None, scale=None, shift=None):
+        return ops.groupnorm(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, silu=silu, x1=x1,
+                             scale=scale, shift=shift)
+
+
+def pack(sd, p, dtype, device, **kw) -> ops.PackedConv:
+    return ops.pack_conv(sd[p + ".weight"], sd.get(p + ".bias"), dtype, device, **kw)
+
+
+class EmbBank:
+    """All per-block embedding projections of a network as ONE f32 GEMM per forward.
+
+    Every ResBlock's ``Linear(emb)`` reads the same [B, E] vector, so their weights are stacked
+    row-wise at load time and evaluated once; blocks then take row-strided views of the result
+    (the 'timestep broadcast' of the reference: src/unet_adm.py:245-247, src/unet_simple.py:121,
+    src/edm_networks.py:187).
+    """
+
+    def __init__(self):
+        self._w: List[torch.Tensor] = []
+        self._b: List[torch.Tensor] = []
+        self._off = 0
+        self.packed: Optional[ops.PackedConv] = None
+
+    def add(self, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> Tuple[int, int]:
+        n = weight.shape[0]
+        self._w.append(weight.detach().float().cpu())
+        self._b.append(torch.zeros(n) if bias is None else bias.detach().float().cpu())
+        off = self._off
+        self._off += n
+        return off, n
+
+    def finalize(self, device):
+        if self._w:
+            self.packed = ops.pack_conv(torch.cat(self._w, 0), torch.cat(self._b, 0), torch.float32, device)
+        self._w, self._b = [], []
+
+    def __call__(self, emb_in: torch.Tensor) -> Optional[torch.Tensor]:
+        if self.packed is None:
+            return None
+        return ops.conv2d(emb_in, self.packed)
+
+
+class SigmaHead:
+    """Flatten -> Linear -> BatchNorm1d(eval) -> act -> Linear, all f32 (src/unet_adm.py:1051-1058,1078-1083).
+
+    BatchNorm in eval mode is an affine map, folded into the first Linear at load time; the
+    activation runs in that GEMM's epilogue.  The feature map arrives NHWC in the compute dtype and is
+    flattened in the reference's NCHW order by the layout kernel.
+    """
+
+    def __init__(self, sd, device, act: int):
+        w, b = sd["fc_layer.1.weight"].double(), sd["fc_layer.1.bias"].double()
+        g, beta = sd["fc_layer.2.weight"].double(), sd["fc_layer.2.bias"].double()
+        mean, var = sd["fc_layer.2.running_mean"].double(), sd["fc_layer.2.running_var"].double()
+        s = g / torch.sqrt(var + 1e-5)
+        self.fc = ops.pack_conv((w * s[:, None]).float(), ((b - mean) * s + beta).float(), torch.float32, device)
+        self.final = ops.pack_conv(sd["final_mlp.weight"], sd["final_mlp.bias"], torch.float32, device)
+        self.act = act
+
+    def __call__(self, h_nhwc: torch.Tensor) -> torch.Tensor:
+        flat = ops.nhwc_to_nchw_f32(h_nhwc).view(h_nhwc.shape[0], -1)
+        h = ops.conv2d(flat, self.fc, act=self.act)
+        return ops.conv2d(h, self.final).view(-1)          # r[b]
+
+
+def first_conv_weight(sd, p, device):
+    """[Cout,Cin,KH,KW] -> [Cout][KH*KW][Cin] f32 for nlc_conv_first."""
+    w = sd[p + ".weight"].float()
+    co, ci, kh, kw = w.shape
+    return (w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci).contiguous().to(device),
+            None if (p + ".bias") not in sd else f32(sd[p + ".bias"], device))
+
+
+def as_f32_cuda(x: torch.Tensor, device) -> torch.Tensor:
+    return x.detach().to(device=device, dtype=torch.float32).contiguous()

@@ -141,7 +141,9 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
             raise ValueError("conv2d: residual shape mismatch")
     emb_stride = 0
     if emb is not None:
-        _need(emb, torch.float32, "conv2d emb")
+        # usually a row-strided view into the network's stacked embedding projections (EmbBank)
+        if emb.dtype != torch.float32 or not emb.is_cuda or emb.dim() != 2 or emb.stride(1) != 1:
+            raise ValueError("conv2d: emb must be a CUDA f32 [B, >=Cout] view with unit inner stride")
         if emb.shape[0] != B or emb.shape[-1] < pw.Cout:
             raise ValueError("conv2d: emb shape mismatch")
         emb_stride = emb.stride(0)

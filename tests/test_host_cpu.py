@@ -1,0 +1,81 @@
+"""CPU-side checks of the host logic: parameter specs vs the reference modules' state_dicts,
+the C-ABI library's exports, and loud failure without a GPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+from tests.util import load_specs, state_dicts
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def build_product(tag):
+    import argparse
+    from diffusion_nlc_amd import script_util
+    cfgs = load_specs()["_configs"]
+    c = dict(cfgs[tag])
+    if tag.startswith("adm"):
+        return script_util.create_sigma_eps_model(**c)
+    if tag.startswith("simple"):
+        ns = argparse.Namespace
+        cfg = ns(model=ns(**{k: c[k] for k in ("ch", "out_ch", "ch_mult", "num_res_blocks", "attn_resolutions", "dropout",
+                                                 "in_channels", "resamp_with_conv", "feat_layer", "type", "sigma_block",
+                                                 "sigma_dropout")}),
+                 data=ns(image_size=c["image_size"]), diffusion=ns(num_diffusion_timesteps=c["num_diffusion_timesteps"]))
+        return script_util.create_simple_sigma_eps_model(cfg)
+    return script_util.create_edm_sigma_eps_model(**c)
+
+
+@pytest.mark.parametrize("tag", ["adm_tiny", "adm_tiny_b", "simple_tiny", "edm_tiny"])
+def test_param_spec_matches_reference_state_dict(tag):
+    """Key names, order, shapes and dtypes equal what the reference modules produced (tests/golden/specs.json)."""
+    specs = load_specs()
+    eps, sig, fshape = build_product(tag)
+    assert list(fshape) == specs[tag]["feat_shape"]
+    for mod, ref in ((eps, specs[tag]["eps"]), (sig, specs[tag]["sigma"])):
+        got = {k: [list(s), str(d).replace("torch.", "")] for k, (s, d) in mod.param_spec().items()}
+        assert list(got.keys()) == list(ref.keys())
+        assert got == ref
+    e, s = state_dicts(tag)
+    eps.load_state_dict(e)
+    sig.load_state_dict(s)
+    with pytest.raises(RuntimeError):
+        eps.load_state_dict({k: v for k, v in list(e.items())[:-1]})
+
+
+def test_library_exports_every_declared_symbol():
+    from diffusion_nlc_amd import _ext
+    header = (ROOT / "include" / "nlc_hip.h").read_text()
+    declared = set(re.findall(r"\b(nlc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"nlc_conv_desc", "nlc_sched_desc"}
+    lib = _ext.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libnlc_hip.so does not export {name}"
+        assert name in _ext.SIGNATURES, f"{name} is declared in nlc_hip.h but not bound in _ext.py"
+    assert set(_ext.SIGNATURES) <= declared
+    assert lib.nlc_version() == 1
+    a, b = _ext.pack_dims(_ext.NLC_BF16)
+    assert a % 16 == 0 and b % 8 == 0
+
+
+def test_argument_validation_without_gpu():
+    """Bad descriptors are rejected on the host before any launch."""
+    from diffusion_nlc_amd import _ext
+    lib = _ext.load()
+    d = _ext.ConvDesc()
+    assert lib.nlc_conv2d(ctypes.byref(d), 7, None) == -1
+    assert b"dtype" in lib.nlc_last_error()
+    assert lib.nlc_attention(None, None, 1, 1, 1, 64, 0, None) == -1
+    assert lib.nlc_groupnorm(None, None, 8, 0, 1, 1, 3, 1e-5, None, None, None, None, 0, 0, None, None, 0, None) == -1
+
+
+def test_no_cpu_fallback():
+    from diffusion_nlc_amd._ext import NlcError
+    eps, sig, _ = build_product("adm_tiny_b")
+    with pytest.raises(NlcError):
+        eps(torch.zeros(1, 3, 32, 32), torch.zeros(1))
+    with pytest.raises(NlcError):
+        sig(torch.zeros(1, 64, 8, 8))
