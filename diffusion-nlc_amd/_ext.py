@@ -59,9 +59,11 @@ class SchedDesc(C.Structure):
         ("sigma_t", C.c_void_p), ("sigma_prev", C.c_void_p),
         ("eps_norm_sumsq", C.c_void_p),
         ("dyn_s", C.c_void_p),
+        ("logvar_ext", C.c_void_p),
         ("x0", C.c_void_p), ("x_prev", C.c_void_p), ("eps_used", C.c_void_p),
         ("B", C.c_int32), ("C", C.c_int32), ("Cnet", C.c_int32), ("HW", C.c_int32),
         ("variant", C.c_int32), ("clip", C.c_int32), ("var_mode", C.c_int32),
+        ("phases", C.c_int32),
         ("eta", C.c_float), ("min_var_coef", C.c_float),
     ]
 

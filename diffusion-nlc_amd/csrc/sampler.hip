@@ -220,17 +220,23 @@ __global__ void sched_step_kernel(const nlc_sched_desc d, int* nan_flag) {
     const float dyn = d.dyn_s ? d.dyn_s[b] : 1.f;
     const float simple_sig = sqrtf(1.0f - d.eta * d.eta);   // math.sqrt(1-eta**2), python double -> f32 scalar
     bool saw_nan = false;
+    const bool do_clip = d.phases == 0 || (d.phases & 1), do_step = d.phases == 0 || (d.phases & 2);
     for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
         const int c = i / d.HW, p = i - c * d.HW;
         const int64_t o = (int64_t)b * n + i;
         float e = sched_eps(d, s, b, c, p);
         const float xt = d.xt[o];
         float x0 = d.x0[o];                                  // pre-clip x0_hat from phase 0
-        if (d.clip == NLC_CLIP_CLAMP) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-        else if (d.clip == NLC_CLIP_DYNAMIC) x0 = fminf(fmaxf(x0, -dyn), dyn) / dyn;
-        if (d.mask) { if (d.mask[(int64_t)c * d.HW + p] != 0.f) x0 = d.known[o]; }
+        if (do_clip) {
+            if (d.clip == NLC_CLIP_CLAMP) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            else if (d.clip == NLC_CLIP_DYNAMIC) x0 = fminf(fmaxf(x0, -dyn), dyn) / dyn;
+            if (d.mask) { if (d.mask[(int64_t)c * d.HW + p] != 0.f) x0 = d.known[o]; }
+            d.x0[o] = x0;
+        }
+        if (!do_step) continue;
         float lv = 0.f;
-        if (d.var_mode == NLC_VAR_LEARNED) {
+        if (d.logvar_ext) lv = d.logvar_ext[o];
+        else if (d.var_mode == NLC_VAR_LEARNED) {
             const float v = d.eps_out[((int64_t)b * d.Cnet + d.C + c) * d.HW + p];
             const float frac = (v + 1.0f) / 2.0f;
             lv = frac * s.max_lv + (1.0f - frac) * s.min_lv;
@@ -288,7 +294,6 @@ __global__ void sched_step_kernel(const nlc_sched_desc d, int* nan_flag) {
                 xp = zp / sqrtf(abp);
             } break;
         }
-        d.x0[o] = x0;
         d.x_prev[o] = xp;
         if (d.eps_used) d.eps_used[o] = e;
         saw_nan |= (xp != xp);
@@ -367,13 +372,15 @@ extern "C" int nlc_sched_x0(const nlc_sched_desc* d, void* stream) {
 
 extern "C" int nlc_sched_step(const nlc_sched_desc* d, int* nan_flag, void* stream) {
     int rc = check_sched(d, "nlc_sched_step"); if (rc) return rc;
-    NLC_REQUIRE(d->x_prev, "nlc_sched_step: null x_prev");
+    NLC_REQUIRE(d->x_prev || d->phases == 1, "nlc_sched_step: null x_prev");
+    NLC_REQUIRE(d->phases >= 0 && d->phases <= 3, "nlc_sched_step: bad phases %d", d->phases);
     NLC_REQUIRE(d->clip >= NLC_CLIP_NONE && d->clip <= NLC_CLIP_DYNAMIC, "nlc_sched_step: bad clip %d", d->clip);
     NLC_REQUIRE(d->clip != NLC_CLIP_DYNAMIC || d->dyn_s, "nlc_sched_step: dynamic clip needs dyn_s");
     NLC_REQUIRE(d->var_mode >= NLC_VAR_NONE && d->var_mode <= NLC_VAR_LEARNED, "nlc_sched_step: bad var_mode %d", d->var_mode);
     const bool needs_noise = (d->variant == NLC_SCHED_DDPM || d->variant == NLC_SCHED_DDPM_ORIG || d->eta > 0.f);
-    NLC_REQUIRE(!needs_noise || d->noise, "nlc_sched_step: this variant/eta needs a noise tensor");
-    NLC_REQUIRE(!needs_noise || d->var_mode != NLC_VAR_NONE || d->variant == NLC_SCHED_DDIM_SIMPLE ||
+    const bool stepping = d->phases == 0 || (d->phases & 2);
+    NLC_REQUIRE(!stepping || !needs_noise || d->noise, "nlc_sched_step: this variant/eta needs a noise tensor");
+    NLC_REQUIRE(!stepping || !needs_noise || d->var_mode != NLC_VAR_NONE || d->logvar_ext || d->variant == NLC_SCHED_DDIM_SIMPLE ||
                     d->variant == NLC_SCHED_DDIM_SIMPLE_ORIG || d->variant == NLC_SCHED_DDIM_SIMPLE_DRAG,
                 "nlc_sched_step: stochastic variant with sampler_var 'none' (the reference raises here too)");
     int gx = cdiv((int64_t)d->C * d->HW, NT * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;

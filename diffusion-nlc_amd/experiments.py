@@ -1,0 +1,318 @@
+"""Sampling loops on the GPU (drop-in for the sampling half of src/experiments.py).
+
+``ImageExperiment.denoise_loop`` keeps the reference's signature and return value
+(src/experiments.py:329-397) but runs every step on the device without host round trips:
+
+    per step   nlc_row_sumsq(xt)                       ||xt||^2 per sample           (refine_prior_sigma)
+               nlc_refine_sigma                        sigma clamp, t lookup, c_in    (:401-419)
+               UNet.encode  -> SigmaModel  (HIP nets)  NLC residual r                 (:420-424)
+               nlc_sigma_correct                       sigma_hat, sigma_prev_hat, t   (:425-431)
+               UNet.forward (HIP net, input scaled by c_in inside the first conv)     (:436-450)
+               nlc_row_sumsq(eps)                      ||eps||^2 per sample           (norm_eps, :457-458)
+               nlc_sched_x0 [+ nlc_dynamic_threshold]  x0_hat (and its 0.99-quantile) (:360-361)
+               nlc_sched_step                          clip, x_prev                   (:361-370)
+
+The per-sample scalars never leave the device; the only host syncs are the ones the reference also
+has: the optional per-step logging copies and the NaN early-break flag (one int per step).
+Noise is drawn on the host from the caller's generator in the reference's order and uploaded.
+"""
+from __future__ import annotations
+
+import math
+from itertools import pairwise
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from ._ext import CLIP_MODES, SCHED_VARIANTS, VAR_MODES, NlcError, SchedDesc
+
+
+class StackedRandomGenerator:
+    """src/experiments.py:71-85, with the per-sample generators on the HOST so that results are
+    reproducible against the CPU reference (SURVEY.md §7 'RNG parity'); draws are uploaded."""
+
+    def __init__(self, device, seeds):
+        self.device = torch.device(device)
+        self.generators = [torch.Generator().manual_seed(int(seed) % (1 << 32)) for seed in seeds]
+
+    def randn(self, size, **kwargs):
+        assert size[0] == len(self.generators)
+        kwargs.pop("device", None)
+        return torch.stack([torch.randn(size[1:], generator=gen, **kwargs) for gen in self.generators]).to(self.device)
+
+    def randn_like(self, input):
+        return self.randn(input.shape, dtype=input.dtype)
+
+
+class ExperimentDiffusion:
+    def __init__(self, model, scheduler, batch_size, data_shape, save_folder, seed=0, device="cpu", dist_train=0,
+                 time_shift=0):
+        self.model = model
+        self.scheduler = scheduler
+        self.device = torch.device(device)
+        self.seed = seed
+        self.batch_size = batch_size
+        self.data_shape = tuple(data_shape)
+        self.shape = (batch_size,) + self.data_shape
+        self.dim = int(np.prod(data_shape))
+        self.dim_coord = len(data_shape)
+        self.save_folder = save_folder
+        self.dist_train = dist_train
+        self.time_shift = time_shift
+        self.clip_kind = "none"
+        self.clip_denoise_fn = lambda x: x
+        self.learn_epsvar = False
+        self.sigma_model = None
+        self.norm_min, self.norm_max = 0.0, 1.0
+        self.fid_fn = None
+        self.gen = self.new_gen()
+
+    # ---- configuration (src/experiments.py:104-114,176-226) -------------------------------------
+    def set_model(self, model=None, sigma_model=None, learn_epsvar=True):
+        if model is not None:
+            self.model = model
+            self.learn_epsvar = learn_epsvar
+        else:
+            self.learn_epsvar = False
+        if sigma_model is not None:
+            self.sigma_model = sigma_model
+
+    def set_norm_maxmin(self, norm_min=None, norm_max=None):
+        self.norm_min = norm_min / math.sqrt(self.dim) if norm_min is not None else 0.0
+        self.norm_max = norm_max / math.sqrt(self.dim) if norm_max is not None else 1.0
+
+    def set_clip_fn(self, clip_fn="none"):
+        """'clamp' | 'dynamic' (0.99-quantile thresholding, max 100) | anything else = identity."""
+        self.clip_kind = clip_fn if clip_fn in ("clamp", "dynamic") else "none"
+        self.clip_denoise_fn = self._clip_tensor
+
+    def _clip_tensor(self, x):
+        if self.clip_kind == "clamp":
+            return x.clamp(-1, 1)
+        if self.clip_kind == "dynamic":
+            s = ops.dynamic_threshold(x.contiguous(), 0.99, 100.0).view(-1, *([1] * (x.dim() - 1)))
+            return torch.clamp(x, -s, s) / s
+        return x
+
+    def fid_helper(self, fid_target, dims=2048):
+        """FID needs pytorch_fid + an InceptionV3 download; optional here: without the
+        package or a target file the metric is reported as NaN instead of failing the run."""
+        try:
+            from pytorch_fid.fid_score import calculate_frechet_distance, compute_statistics_of_path
+            from pytorch_fid.inception import InceptionV3
+            with np.load(fid_target) as f:
+                m1, s1 = f["mu"][:], f["sigma"][:]
+            model = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]]).to(self.device)
+            self.fid_fn = lambda path: calculate_frechet_distance(m1, s1, *compute_statistics_of_path(path, model, 128, dims, self.device, 1))
+        except Exception:                         # noqa: BLE001 - optional dependency
+            self.fid_fn = lambda path: float("nan")
+
+    # ---- small helpers (src/experiments.py:255-325) ----------------------------------------------
+    def batched_t(self, t, batch_size=None):
+        return torch.ones(self.batch_size if batch_size is None else batch_size, dtype=int, device=self.device) * t
+
+    def new_gen(self, seed=None):
+        return torch.manual_seed(self.seed if seed is None else seed)
+
+    def get_noise(self, shape=None, gen=None, norm_noise=False):
+        noise = torch.randn(self.shape if shape is None else shape, generator=self.gen if gen is None else gen)
+        noise = noise.to(self.device)
+        if norm_noise:
+            ss = ops.row_sumsq(noise)
+            noise = ops.scale_rows(noise, math.sqrt(self.dim) / torch.clamp(ss.sqrt(), min=1e-12))
+        return noise
+
+    def convert_coordinate(self, xt, sigma=None, t=None):
+        alpha_bar = 1 / (torch.as_tensor(sigma) ** 2 + 1) if sigma is not None else self.scheduler.get_alpha_bar(t)
+        return self._scale(xt, alpha_bar.sqrt())
+
+    def inv_convert_coordinate(self, zt, sigma=None, t=None):
+        alpha_bar = 1 / (torch.as_tensor(sigma) ** 2 + 1) if sigma is not None else self.scheduler.get_alpha_bar(t)
+        return self._scale(zt, 1 / alpha_bar.sqrt())
+
+    def _scale(self, x, s):
+        s = torch.as_tensor(s, dtype=torch.float32).reshape(-1)
+        if s.numel() == 1:
+            return ops.scale_rows(x.contiguous(), None, float(s))
+        return ops.scale_rows(x.contiguous(), s.to(x.device).contiguous(), 1.0)
+
+    def get_noise_xt(self, shape=None, gen=None, norm_noise=False, t=None, sigma=None):
+        """Initial state: drawn AND scaled on the host exactly as the reference does (z / sqrt(alpha_bar),
+        src/experiments.py:284-293,322-325), then uploaded once per batch."""
+        z = torch.randn(self.shape if shape is None else shape, generator=self.gen if gen is None else gen)
+        if norm_noise:
+            z = math.sqrt(self.dim) * z / torch.clamp(torch.linalg.vector_norm(z, dim=tuple(range(1, z.dim())), keepdim=True), min=1e-12)
+        alpha_bar = 1 / (torch.as_tensor(sigma) ** 2 + 1) if sigma is not None else self.scheduler.get_alpha_bar(t)
+        xt = z / alpha_bar.sqrt()
+        return xt.to(self.device, torch.float32).contiguous(), z.to(self.device)
+
+    def pred_xt(self, xt, t, sigma=None, batch_t=True):
+        return self.model(self.convert_coordinate(xt, sigma, t), self._t_vec(t, len(xt), batch_t))
+
+    def encode_xt(self, xt, t, sigma=None, batch_t=True):
+        return self.model.encode(self.convert_coordinate(xt, sigma, t), self._t_vec(t, len(xt), batch_t))
+
+    def forward_and_encode_xt(self, xt, t, sigma=None, batch_t=True):
+        return self.model.forward_and_encode(self.convert_coordinate(xt, sigma, t), self._t_vec(t, len(xt), batch_t))
+
+    def _t_vec(self, t, n, batch_t):
+        t = torch.as_tensor(t)
+        if batch_t:
+            t = torch.ones(n) * t
+        return t.reshape(-1).float()
+
+    # ---- the device loop ----------------------------------------------------------------------------
+    def _state(self, B):
+        dev = self.device
+        st = getattr(self, "_dev_state", None)
+        if st is None or st["B"] != B or st["dev"] != dev:
+            f = lambda: torch.empty(B, device=dev, dtype=torch.float32)
+            st = dict(B=B, dev=dev, sigma_t=f(), sigma_prev=f(), t=f(), c_in=f(),
+                      nan=torch.zeros(1, device=dev, dtype=torch.int32))
+            self._dev_state = st
+        return st
+
+    def _nlc_step(self, xt, t_sched, sigma_sched, sigma_prev_sched, style, norm_eps, refine):
+        """get_denoise_vector (src/experiments.py:399-460) on the device.  Returns (eps_out, eps_sumsq)."""
+        S = self.scheduler
+        B = xt.shape[0]
+        st = self._state(B)
+        sumsq = ops.row_sumsq(xt) if refine else None
+        ops.refine_sigma(sumsq, math.sqrt(self.dim), self.norm_max, self.norm_min, float(sigma_sched),
+                         float(sigma_prev_sched), refine, S.device_sigmas(self.device) if refine else None,
+                         int(t_sched), self.time_shift, st["sigma_t"], st["sigma_prev"], st["t"], st["c_in"])
+        if "pred" in style:
+            if self.sigma_model is None:
+                raise NlcError("style '%s' needs a sigma model (set_model)" % style)
+            feat = self.model.run(xt, st["t"], mode="encode", in_scale=st["c_in"], feat_nhwc=True)
+            r = self.sigma_model.run_nhwc(feat)
+            ops.sigma_correct(r, style != "pred", S.device_sigmas(self.device), st["sigma_t"], st["sigma_prev"], st["t"],
+                              st["c_in"])
+        eps_out = self.model.run(xt, st["t"], mode="forward", in_scale=st["c_in"])
+        C = self.data_shape[0]
+        if self.learn_epsvar and eps_out.shape[1] != 2 * C:
+            raise NlcError("learn_epsvar expects a 2C-channel network output")
+        es = ops.row_sumsq(eps_out, d_used=self.dim) if norm_eps else None
+        return eps_out, es
+
+    @torch.no_grad()
+    def get_denoise_vector(self, xt, t, sigma_t, sigma_prev, style="base", norm_eps=False, refine_prior_sigma=False,
+                           chunk_size=2):
+        """Reference-shaped wrapper: returns (eps_mean, eps_logvar, sigma_t, sigma_prev) as (B,..) GPU tensors."""
+        xt = xt.to(self.device, torch.float32).contiguous()
+        B, C = xt.shape[0], self.data_shape[0]
+        eps_out, es = self._nlc_step(xt, int(t), float(sigma_t), float(sigma_prev), style, norm_eps, refine_prior_sigma)
+        st = self._state(B)
+        eps = eps_out[:, :C].contiguous()
+        if es is not None:
+            eps = ops.scale_rows(eps, math.sqrt(self.dim) / torch.clamp(es.sqrt(), min=1e-12))
+        sig_t, sig_p = st["sigma_t"].view(B, 1, 1, 1).clone(), st["sigma_prev"].view(B, 1, 1, 1).clone()
+        learned = eps_out[:, C:] if self.learn_epsvar else None
+        return eps, self.scheduler.get_eps_logvar(sig_t, sig_p, learned), sig_t, sig_p
+
+    @torch.no_grad()
+    def denoise_loop(self, shape, gen=None, norm_init_noise=False, style="base", constrain_fn=None, norm_eps=False,
+                     refine_prior_sigma=False, xT=None, return_log=True, chunk_size=2, sigma_pred_threshold=1000,
+                     new_eta=None, constrain_loss=None, return_best=True, free_const_steps=-1, noise_list=None):
+        """src/experiments.py:329-397.  ``noise_list`` (optional) supplies the per-step N(0,1) draws that
+        stochastic samplers consume; by default they come from the global CPU generator, one
+        ``randn(shape)`` per step, in step order."""
+        S = self.scheduler
+        if getattr(S, "continuous_t", False):
+            raise NotImplementedError("continuous-t schedules (sigma_style Linear/Scaled, redesign) are not on the HIP path yet")
+        S.reset_state()
+        dev = self.device
+        sig_host = S.sampling_sigmas.detach().cpu().float()
+        ts_host = S.timesteps.detach().cpu()
+        if xT is None:
+            xt, zt = self.get_noise_xt(shape=shape, gen=gen, norm_noise=norm_init_noise, sigma=sig_host[0])
+        else:
+            xt = xT.to(dev, torch.float32).contiguous()
+            zt = self.convert_coordinate(xt, sigma=sig_host[0]) if return_log else None
+        B, C = xt.shape[0], xt.shape[1]
+        HW = xt.numel() // (B * C)
+        st = self._state(B)
+        z_list, eps_list, x0_prec_list, x0_postc_list, const_loss_list = [], [], [], [], []
+        if return_log:
+            z_list = [zt.cpu()]
+        eta0 = S.eta
+        variant = SCHED_VARIANTS[S.variant]
+        best_val, best_x0 = 10000, xt
+        x0 = xt
+        st["nan"].zero_()
+        for ind, (t, t_prev) in enumerate(pairwise(ts_host.tolist())):
+            if ind == S.num_inference_steps - 1 and new_eta is not None:
+                S.eta = new_eta
+            cur_style, cur_refine = style, bool(refine_prior_sigma)
+            if t > sigma_pred_threshold:
+                cur_style, cur_refine = "base", False
+            eps_out, es = self._nlc_step(xt, t, sig_host[ind], sig_host[ind + 1], cur_style, bool(norm_eps), cur_refine)
+            stochastic = S.eta > 0 or S.variant in ("ddpm", "ddpm_orig")
+            noise = None
+            if stochastic:
+                noise = (noise_list[ind] if noise_list is not None else torch.randn(xt.shape)).to(dev, torch.float32).contiguous()
+            x0 = torch.empty_like(xt)
+            x_prev = torch.empty_like(xt)
+            eps_used = torch.empty_like(xt) if return_log else None
+            var_mode = VAR_MODES[S.sampler_var]
+            if var_mode == VAR_MODES["learned"] and not self.learn_epsvar:
+                raise NlcError("sampler_var 'learned' needs a network with learned variance (learn_epsvar)")
+            d = SchedDesc(xt=xt.data_ptr(), eps_out=eps_out.data_ptr(), noise=None if noise is None else noise.data_ptr(),
+                          sigma_t=st["sigma_t"].data_ptr(), sigma_prev=st["sigma_prev"].data_ptr(),
+                          eps_norm_sumsq=None if es is None else es.data_ptr(), x0=x0.data_ptr(), x_prev=x_prev.data_ptr(),
+                          eps_used=None if eps_used is None else eps_used.data_ptr(), B=B, C=C, Cnet=eps_out.shape[1], HW=HW,
+                          variant=variant, clip=CLIP_MODES[self.clip_kind], var_mode=var_mode, phases=0,
+                          eta=float(S.eta), min_var_coef=float(S.min_var_coef))
+            ops.sched_x0(d)
+            dyn = None
+            if self.clip_kind == "dynamic":
+                dyn = ops.dynamic_threshold(x0, 0.99, 100.0)
+                d.dyn_s = dyn.data_ptr()
+            x0_hat = None
+            use_constraint = constrain_fn is not None and (free_const_steps <= 0 or ind <= free_const_steps)
+            if use_constraint or (return_log and constrain_fn is not None):
+                d.phases = 1                                   # clip only
+                ops.sched_step(d)
+                x0_hat = x0.clone() if return_log else x0
+                if use_constraint:
+                    x0 = constrain_fn(x0).to(dev, torch.float32).contiguous()
+                    d.x0 = x0.data_ptr()
+                d.phases = 2
+                ops.sched_step(d, st["nan"])
+            else:
+                ops.sched_step(d, st["nan"])
+                x0_hat = x0
+            S.i += 1
+            xt_prev, xt = xt, x_prev
+            if constrain_loss is not None:
+                const, _ = constrain_loss(x0.clamp(-1, 1))
+                const_val = torch.mean(const)
+                if const_val < best_val:
+                    best_x0, best_val = x0, const_val
+                if return_log:
+                    const_loss_list.append(const.cpu())
+            else:
+                best_x0 = x0
+            if return_log:
+                z_list.append(ops.scale_rows(xt, torch.sqrt(1 / (st["sigma_prev"] ** 2 + 1))).cpu())   # logging only
+                eps_list.append(eps_used.cpu())
+                x0_prec_list.append(x0_hat.cpu())
+                x0_postc_list.append(x0.cpu())
+            if self.check_nan and int(st["nan"].item()) != 0:       # torch.isnan(xt).any() -> break (:389)
+                break
+        S.eta = eta0
+        out = (best_x0 if return_best else x0).cpu()
+        return out, [z_list, eps_list, x0_prec_list, x0_postc_list, const_loss_list]
+
+    check_nan = True
+
+
+class ImageExperiment(ExperimentDiffusion):
+    """src/experiments.py:553-560 (sampling only; training of the sigma net is out of scope)."""
+
+    def __init__(self, model, scheduler, batch_size=64, data_shape=(3, 32, 32), seed=0, device="cuda:0", save_folder="./",
+                 dist_train=False, time_shift=0):
+        super().__init__(model=model, scheduler=scheduler, batch_size=batch_size, data_shape=data_shape,
+                         save_folder=save_folder, seed=seed, device=device, dist_train=dist_train, time_shift=time_shift)

@@ -196,9 +196,11 @@ typedef struct nlc_sched_desc {
     const float* sigma_t; const float* sigma_prev;   /* [B] */
     const float* eps_norm_sumsq;  /* [B] or NULL */
     const float* dyn_s;           /* [B] or NULL (dynamic threshold value) */
+    const float* logvar_ext;      /* [B][C][HW] caller-supplied log-variance (overrides var_mode) or NULL */
     float* x0; float* x_prev; float* eps_used;       /* eps_used may be NULL */
     int32_t B, C, Cnet, HW;
     int32_t variant, clip, var_mode;
+    int32_t phases;               /* bit 0: clip (+mask) x0 in place ; bit 1: write x_prev.  0 means both */
     float eta, min_var_coef;
 } nlc_sched_desc;
 int nlc_sched_x0(const nlc_sched_desc* d, void* stream);
