@@ -103,6 +103,9 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
 # --------------------------------------------------------------------------------------
 # kernels
 # --------------------------------------------------------------------------------------
+# When bench.py sets this to a list, every nlc_conv2d launch appends (start_event, end_event,
+# algorithmic FLOPs = 2*M*N*K of the direct convolution, dtype).
+CONV_PROFILE = None
 def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
            pad: Optional[tuple] = None, out_hw: Optional[tuple] = None, upsample2x: bool = False,
            emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
@@ -153,7 +156,16 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
                  out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC)
-    check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
+    prof = CONV_PROFILE
+    if prof is not None:
+        # bench.py's roofline leg: HIP events on the launch stream around this one kernel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
+        e1.record()
+        prof.append((e0, e1, 2.0 * B * Hout * Wout * pw.Cout * pw.KH * pw.KW * pw.Cin, dt))
+    else:
+        check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
     if linear and not out_nchw_f32:
         out = out.view(B, pw.Cout)
     return out

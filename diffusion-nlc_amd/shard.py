@@ -1,0 +1,78 @@
+"""Sample-level sharding of the sampling run over the GPUs of one node.
+
+Independent samples never interact on the unconstrained path, so the run shards by WHOLE
+reference-sized batches: rank r owns global batches r, r+W, r+2W, ...  Every rank replays the
+reference's single host generator in the reference's order (one ``randn(batch_shape)`` per global
+batch, image_sample.py:529 / src/experiments.py:268) and keeps only its own draws, so the
+gathered result equals the single-process run bit for bit.  The only collective is one
+all-gather of the finished samples (RCCL over xGMI with backend 'nccl'; 'gloo' in the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def owned_batches(n_batches: int, world: int, rank: int) -> List[int]:
+    return list(range(rank, n_batches, world))
+
+
+def draw_initial_noise(batch_shape: Sequence[int], n_batches: int, seed: int, world: int, rank: int) -> List[torch.Tensor]:
+    """Replay the reference's generator for ALL global batches, keep this rank's (host tensors)."""
+    gen = torch.Generator().manual_seed(seed)
+    mine = set(owned_batches(n_batches, world, rank))
+    out = []
+    for j in range(n_batches):
+        z = torch.randn(tuple(batch_shape), generator=gen)
+        if j in mine:
+            out.append(z)
+    return out
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """(rank, world, local_rank) from torchrun's environment; initialises torch.distributed when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def gather_samples(local: torch.Tensor, n_batches: int, world: int, rank: int) -> torch.Tensor:
+    """All-gather per-rank results [n_local, B, ...] and restore global batch order -> [n_batches, B, ...].
+
+    Ranks may own different numbers of batches when world does not divide n_batches; shorter ranks are
+    padded to the maximum for the collective and the padding is dropped afterwards."""
+    if world == 1:
+        return local
+    n_max = (n_batches + world - 1) // world
+    pad = n_max - local.shape[0]
+    if pad:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    gathered = local.new_empty((world,) + tuple(local.shape))
+    dist.all_gather_into_tensor(gathered.view(-1), local.contiguous().view(-1))
+    out = local.new_empty((n_batches,) + tuple(local.shape[1:]))
+    for r in range(world):
+        for i, j in enumerate(owned_batches(n_batches, world, r)):
+            out[j] = gathered[r, i]
+    return out
+
+
+def sample_sharded(run_batch: Callable[[torch.Tensor], torch.Tensor], batch_shape: Sequence[int], n_batches: int,
+                   seed: int, world: int, rank: int, device) -> torch.Tensor:
+    """Run ``run_batch(z) -> x`` on this rank's batches and all-gather: returns [n_batches, B, ...] on ``device``."""
+    zs = draw_initial_noise(batch_shape, n_batches, seed, world, rank)
+    outs = [run_batch(z).to(device) for z in zs]
+    local = torch.stack(outs) if outs else torch.empty((0,) + tuple(batch_shape), device=device)
+    return gather_samples(local, n_batches, world, rank)

@@ -247,7 +247,7 @@ def gen_loops(models):
     # ADM: learned variance + dynamic clip (imagenet preset, image_sample.py:153-161), and eta>0 DDIM
     run("adm_tiny", 64, steps=10, var="learned", clip="dynamic", norm_max=440.0 * 64 / 256, name="loop_adm_dynamic")
     run("adm_tiny", 64, steps=8, var="learned", eta=0.85, clip="dynamic", norm_max=110.0, name="loop_adm_eta")
-    run("adm_tiny_b", 32, steps=8, sampler="ddpm", var="fixedlarge", clip="none", name="loop_admb_ddpm")
+    run("adm_tiny_b", 32, steps=8, sampler="ddpm", var="fixedlarge", clip="clamp", name="loop_admb_ddpm")
 
     # EDM / Heun + NLC (BASELINE config 3, reduced)
     eps, sig, _ = models["edm_tiny"]
