@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""DDIM-family sampling entry point with the reference's flags (drop-in for image_sample.py).
+
+Same flag names, defaults and method presets as the reference (image_sample.py:32-96,143-268) and the
+same call order in ``main`` (:712-860): build models -> load checkpoints -> sampler -> ImageExperiment
+-> evaluate_unconstraint -> results.json.  Everything numeric runs on the HIP path of
+diffusion-nlc_amd/.  Differences, all on side effects the reference hard-codes:
+
+* FID (pytorch_fid + InceptionV3 download) and PNG writing are optional: missing packages/files are
+  skipped, FID is reported as NaN.
+* per-step logging (``return_log``, hard-coded True in the reference's main, :822) is the flag
+  ``--return_log`` (default 0): the 2.5 GB-per-batch history is only copied to the host when asked for.
+* ``--synthetic NAME`` (extension): run without ``store/`` / ``results/`` files, with a built-in model
+  configuration and the deterministic filler weights (the reference ships neither configs nor checkpoints).
+* ``--sampling project`` (projection_loop, σ-redesign, continuous t) is a SURVEY §8 "next" row and raises
+  NotImplementedError; so does any ``--constraint`` other than ``none``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import random
+import shutil
+import sys
+from pathlib import Path
+from time import time
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from src.experiments import ImageExperiment                                    # noqa: E402
+from src.schedulers import get_sampler                                          # noqa: E402
+from src.script_util import create_sigma_eps_model, create_simple_sigma_eps_model   # noqa: E402
+from src.utils import get_model_size                                            # noqa: E402
+
+SYNTHETIC = {
+    # name -> (yaml-equivalent config, dataset preset name)
+    "imagenet256": (dict(model=dict(type="openai", image_size=256, num_channels=256, num_res_blocks=2, learn_sigma=True,
+                                    attention_resolutions="32,16,8", num_head_channels=64, use_scale_shift_norm=True,
+                                    resblock_updown=True, use_fp16=True, use_new_attention_order=False),
+                         diffusion=dict(num_diffusion_timesteps=1000, beta_schedule="linear"),
+                         data=dict(dataset="ImageNet", image_size=256, channels=3, subset_1k=False)), "imagenet"),
+    "cifar_tiny": (dict(model=dict(type="simple", ch=64, out_ch=3, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[16],
+                                   dropout=0.0, in_channels=3, resamp_with_conv=True, use_fp16=False),
+                        diffusion=dict(num_diffusion_timesteps=1000, beta_schedule="linear"),
+                        data=dict(dataset="CIFAR10", image_size=32, channels=3, subset_1k=False)), "cifar10"),
+}
+
+
+def dict2namespace(d):
+    ns = argparse.Namespace()
+    for k, v in d.items():
+        setattr(ns, k, dict2namespace(v) if isinstance(v, dict) else v)
+    return ns
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    a = p.add_argument
+    a("--config", type=str, default="cifar10", choices=["cifar10", "imagenet", "celeba", "celeba_hq"])
+    a("--config_path", type=str, default="cifar10_adm")
+    a("--constraint", type=str, default="none", choices=["none", "sr_bicubic", "sr_averagepooling", "deblur_gauss",
+                                                           "colorization", "cs_walshhadamard", "inpainting", "inpainting_half"])
+    a("--constraint_proj", type=str, default="svd", choices=["none", "simple", "svd", "simple_gd", "svd_gd", "ddrm"])
+    a("--constraint_scale", type=float, default=4.0)
+    a("--constraint_lr", type=float, default=10)
+    a("--constraint_iter", type=int, default=10)
+    a("--constraint_loss", type=str, default="l1", choices=["l1", "l2"])
+    a("--prior_xt", type=int, default=0)
+    a("--norm_eps", type=int, default=0)
+    a("--sigma_type", type=str, default="pred", choices=["base", "pred", "pred_partial"])
+    a("--sampling", type=str, default="project", choices=["denoise", "project"])
+    a("--norm_init_noise", type=int, default=0)
+    a("--redesign_sigma", type=int, default=1)
+    a("--min_sigma", type=float, default=0.003)
+    a("--max_sigma", type=float, default=0.02)
+    a("--sigma_gamma", type=float, default=1.0)
+    a("--cycle_size", type=int, default=10)
+    a("--max_T", type=int, default=10)
+    a("--sampler", type=str, default="ddim_simple_orig", choices=["ddpm", "ddim", "ge", "ddim_simple", "ddim_orig", "ddpm_orig",
+                                                                     "ddim_simple_orig", "ddim_simple_drag"])
+    a("--num_timesteps", type=int, default=100)
+    a("--start_sigma", type=float, default=100)
+    a("--end_sigma", type=float, default=0)
+    a("--start_t", type=int, default=-1)
+    a("--end_t", type=int, default=-1)
+    a("--sigma_style", type=str, default="DDIM", choices=["Linear", "DDIM", "Scaled"])
+    a("--linear_scale", type=float, default=1.0)
+    a("--sampler_var", type=str, default="learned", choices=["learned", "fixedsmall", "fixedlarge", "none"])
+    a("--eta", type=float, default=0.85)
+    a("--new_eta", type=float, default=None)
+    a("--refine_sigma", type=int, default=1)
+    a("--continuous_t", type=int, default=1)
+    a("--final_alpha_one", type=int, default=1)
+    a("--time_shift", type=int, default=0)
+    a("--sigma_estimate", type=str, default="1000")
+    a("--sigma_pred_threshold", type=int, default=960)
+    a("--clip_fn", type=str, default="none", choices=["none", "clamp", "dynamic"])
+    a("--recal_sigma_prev", type=int, default=1)
+    a("--batch_size", type=int, default=10)
+    a("--device", type=str, default="cuda:0")
+    a("--seed", type=int, default=1234)
+    a("--result_dir", type=str, default="results")
+    a("--test_dir", type=str, default="temp2")
+    a("--sample_size", type=int, default=1000)
+    a("--save_folder", type=str, default=None)
+    a("--save_flag", type=str, default="0")
+    a("--sample_overwrite", type=int, default=0)
+    a("--load_folder", type=str, default="7")
+    a("--load_eps", type=str, default=None)
+    a("--load_sigma", type=str, default="results/cifar10/7/ema_sigma_ckpt_299.pt")
+    a("--fid_target", type=str, default=None)
+    a("--method", type=str, default="pred_denoise_base",
+      choices=["default", "base", "pred_denoise_base", "pred_denoise_proj", "pred_denoise_proj_arbit", "pred_proj",
+               "pred_denoise_base_nonorm", "pred_denoise_base_norefine", "pred_partial_denoise_base"])
+    # extensions (see module docstring)
+    a("--synthetic", type=str, default=None, choices=sorted(SYNTHETIC))
+    a("--return_log", type=int, default=0)
+    a("--save_png", type=int, default=1)
+    return p
+
+
+def apply_presets(args):
+    """Dataset presets and --method presets (image_sample.py:143-268)."""
+    per_dataset = {"cifar10": dict(norm_max=54.63, norm_min=0, clip_fn="clamp", sampler_var="learned"),
+                   "imagenet": dict(norm_max=440.0, norm_min=0, clip_fn="dynamic", sampler_var="learned"),
+                   "celeba": dict(norm_max=110, norm_min=-2, clip_fn="clamp", sampler_var="learned"),
+                   "celeba_hq": dict(norm_max=397.0, norm_min=0.0, sampler_var="fixedsmall")}
+    args.norm_max = args.norm_min = None
+    for k, v in per_dataset.get(args.config, {}).items():
+        setattr(args, k, v)
+    denoise = dict(sampling="denoise", sigma_style="DDIM", redesign_sigma=0, continuous_t=0)
+    table = {
+        "base": dict(denoise, sigma_type="base", norm_eps=False, refine_sigma=0),
+        "pred_denoise_base": dict(denoise, sigma_type="pred", norm_eps=True, refine_sigma=1),
+        "pred_partial_denoise_base": dict(denoise, sigma_type="pred_partial", norm_eps=True, refine_sigma=1),
+        "pred_denoise_base_nonorm": dict(denoise, sigma_type="pred", norm_eps=False, refine_sigma=1),
+        "pred_denoise_base_norefine": dict(denoise, sigma_type="pred", norm_eps=True, refine_sigma=0),
+        "pred_denoise_proj": dict(sampling="denoise", sigma_type="pred", sigma_style="Linear", norm_eps=True, redesign_sigma=0, continuous_t=1),
+        "pred_denoise_proj_arbit": dict(sampling="denoise", sigma_type="pred", sigma_style="Linear", norm_eps=True, redesign_sigma=1, continuous_t=1),
+    }
+    m = args.method
+    if m in table:
+        for k, v in table[m].items():
+            setattr(args, k, v)
+        if m == "pred_denoise_proj_arbit" and args.max_T >= 50:
+            args.num_timesteps, args.cycle_size = int(0.8 * args.max_T), int(0.1 * args.max_T)
+        else:
+            args.num_timesteps = args.max_T
+    elif "pred_proj" in m:
+        for k, v in dict(sampling="project", sigma_type="pred", sigma_style="Linear", norm_eps=True, redesign_sigma=1, continuous_t=1).items():
+            setattr(args, k, v)
+    if args.sigma_type == "base":
+        args.norm_eps, args.sampling, args.redesign_sigma, args.continuous_t, args.refine_sigma = False, "denoise", 0, 0, 0
+    else:
+        args.norm_eps = True
+    return args
+
+
+def get_args(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.config_path is None:
+        args.config_path = args.config
+    rates = [float(x) for x in args.sigma_estimate]
+    s = sum(rates)
+    rates = [round(x / s, 2) for x in rates]
+    rates[0] += 1 - sum(rates)
+    args.sigma_estimate_rate = rates
+    if args.synthetic:
+        cfg, preset = SYNTHETIC[args.synthetic]
+        args.config = preset
+        config = dict2namespace(cfg)
+        saved = dict(load_eps=None, fid_target=None, sigma_block=2, sigma_dropout=0.0, use_sigma_fp16=cfg["model"].get("use_fp16", False))
+        args.test_dir = os.path.join(args.test_dir, args.synthetic, args.constraint)
+    else:
+        import yaml
+        args.result_dir = os.path.join(args.result_dir, args.config_path, args.load_folder)
+        args.test_dir = os.path.join(args.test_dir, args.config, args.constraint)
+        with open(os.path.join(args.result_dir, "args.json")) as f:       # the sigma-net training run's arguments (:112-121)
+            saved = json.load(f)
+        with open(os.path.join("store", "config", args.config_path + ".yml")) as f:
+            config = dict2namespace(yaml.safe_load(f))
+    args.load_eps, args.fid_target = saved["load_eps"], saved["fid_target"]
+    args.sigma_block = 2 if args.config == "imagenet" else saved["sigma_block"]
+    args.sigma_dropout, args.use_sigma_fp16 = saved["sigma_dropout"], saved["use_sigma_fp16"]
+    config.model.use_sigma_fp16, config.model.sigma_block, config.model.sigma_dropout = args.use_sigma_fp16, args.sigma_block, args.sigma_dropout
+    if "feat_layer" in saved:
+        config.model.feat_layer = saved["feat_layer"]
+    elif not hasattr(config.model, "feat_layer"):
+        config.model.feat_layer = 1
+    return apply_presets(args), config
+
+
+def save_png(img, path):
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    arr = (img.clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    Image.fromarray(arr).save(path)
+
+
+@torch.no_grad()
+def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=False, style="base", sampling="denoise",
+                          norm_eps=False, refine_prior_sigma=False, sigma_pred_threshold=1000, new_eta=None,
+                          return_log=False, save_images=True):
+    """image_sample.py:522-569: ceil(n/B) full batches from ONE host generator, skip batches whose PNGs exist."""
+    if sampling == "project":
+        raise NotImplementedError("projection_loop is a SURVEY §8 'next' row (f-2); use --sampling denoise presets")
+    B = experiment.batch_size
+    shape = (B,) + experiment.data_shape
+    gen = experiment.new_gen()
+    logs = []
+    for i in range(math.ceil(n_samples / B)):
+        paths = [os.path.join(images_dir, f"00-{i:05}-{j:03}.png") for j in range(B)]
+        if save_images and all(os.path.exists(p) for p in paths):
+            print("skip images for:", f"00-{i:05}-(000~{B - 1:03}).png")
+            continue
+        t1 = time()
+        sample, return_list = experiment.denoise_loop(shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
+                                                      constrain_fn=None, norm_eps=norm_eps, refine_prior_sigma=refine_prior_sigma,
+                                                      return_log=return_log, chunk_size=1, sigma_pred_threshold=sigma_pred_threshold,
+                                                      new_eta=new_eta)
+        print("time:", time() - t1)
+        logs.append(return_list)
+        sample = sample.add(1).div(2).clamp(0, 1)
+        if save_images:
+            for img, p in zip(sample, paths):
+                save_png(img, p)
+        print(f"done batches:{i}/{math.ceil(n_samples / B)}")
+    fid = experiment.fid_fn(images_dir) if experiment.fid_fn is not None else float("nan")
+    return {"fid": fid}, logs
+
+
+def main(args, config):
+    if args.constraint != "none":
+        raise NotImplementedError("restoration constraints are a SURVEY §8 'next' row (f-1)")
+    if args.save_folder is not None:
+        args.test_dir = args.save_folder
+    else:
+        i = 0
+        while os.path.exists(os.path.join(args.test_dir, str(i))):
+            i += 1
+        args.test_dir = os.path.join(args.test_dir, str(i))
+    os.makedirs(args.test_dir, exist_ok=True)
+    with open(os.path.join(args.test_dir, "args.json"), "w") as f:
+        json.dump({k: (str(v) if k == "device" else v) for k, v in vars(args).items()}, f)
+    if args.seed is not None:
+        random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
+
+    mc = config.model
+    if mc.type == "openai":
+        model, sigma_model, _ = create_sigma_eps_model(**vars(mc))
+    else:
+        model, sigma_model, _ = create_simple_sigma_eps_model(config)
+    print("eps model size:", get_model_size(model))
+    print("sigma model size:", get_model_size(sigma_model))
+    if args.synthetic:
+        from diffusion_nlc_amd.filler import fill_state_dict
+        model.load_state_dict(fill_state_dict(model.state_dict(), seed=0))
+        sigma_model.load_state_dict(fill_state_dict(sigma_model.state_dict(), seed=1, overrides={"final_mlp.weight": 0.1, "final_mlp.bias": 0.5}))
+    else:
+        model.load_state_dict(torch.load(args.load_eps, map_location="cpu"))
+        sigma_model.load_state_dict(torch.load(args.load_sigma, map_location="cpu"))
+    model.eval().to(args.device)
+    sigma_model.eval().to(args.device)
+    if getattr(mc, "use_fp16", False):
+        model.convert_to_fp16()
+    if getattr(mc, "use_sigma_fp16", False):
+        sigma_model.convert_to_fp16()
+
+    dc = config.diffusion
+    sampler = get_sampler(args.sampler, dc.num_diffusion_timesteps, args.num_timesteps, beta_schedule=dc.beta_schedule,
+                          sigma_style=args.sigma_style, set_alpha_to_one=args.final_alpha_one, start_sigma=args.start_sigma,
+                          end_sigma=args.end_sigma, sampler_var=args.sampler_var, continuous_t=args.continuous_t,
+                          linear_scale=args.linear_scale, eta=args.eta, norm_eps=args.norm_eps, start_t=args.start_t, end_t=args.end_t)
+    if args.redesign_sigma and args.max_T > args.num_timesteps:
+        raise NotImplementedError("sigma redesign (image_sample.py:788-800) needs continuous t: SURVEY §8 'next' row f-2")
+    sampler.to(args.device)
+
+    d = config.data
+    experiment = ImageExperiment(model, sampler, batch_size=args.batch_size, data_shape=(d.channels, d.image_size, d.image_size),
+                                 seed=args.seed, device=args.device, save_folder=args.test_dir, dist_train=False,
+                                 time_shift=args.time_shift)
+    experiment.set_model(model, sigma_model, learn_epsvar=mc.type == "openai")
+    experiment.fid_helper(args.fid_target)
+    experiment.set_norm_maxmin(args.norm_min, args.norm_max)
+    experiment.set_clip_fn(args.clip_fn)
+
+    images_dir = os.path.join(args.test_dir, args.save_flag, "images")
+    if os.path.exists(images_dir) and args.sample_overwrite:
+        shutil.rmtree(images_dir)
+    os.makedirs(images_dir, exist_ok=True)
+    log_dict, return_lists = evaluate_unconstraint(
+        experiment, args.sample_size, images_dir, norm_init_noise=args.norm_init_noise, style=args.sigma_type,
+        sampling=args.sampling, norm_eps=args.norm_eps, refine_prior_sigma=args.refine_sigma,
+        sigma_pred_threshold=args.sigma_pred_threshold, new_eta=args.new_eta, return_log=bool(args.return_log),
+        save_images=bool(args.save_png))
+    if args.return_log:
+        torch.save(return_lists, os.path.join(args.test_dir, args.save_flag, "results_dump.pt"))
+    with open(os.path.join(args.test_dir, args.save_flag, "results.json"), "w") as f:
+        json.dump(log_dict, f)
+    print(log_dict)
+    print("evaluate done")
+    return log_dict
+
+
+if __name__ == "__main__":
+    main(*get_args())
