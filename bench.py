@@ -74,7 +74,8 @@ def cpu_baseline(cfg, max_seconds=240.0):
     from oracle import adm
     from oracle.loop import DiffusionOracle
     from oracle.sched import get_sampler
-    cores = os.cpu_count() or 1
+    # the GPU box shares its host: a 1-GPU slot owns 16 cores (os.cpu_count() reports the whole machine)
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     ucfg, scfg, _ = adm.configs_from_factory(**cfg)
     eps_m, sig_m, _ = create_sigma_eps_model(**cfg)
@@ -172,15 +173,24 @@ def main():
     }
     if rank == 0:
         if prof:
-            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, d in prof if d == dtype)
-            tot_fl = sum(f for _, _, f, d in prof if d == dtype)
-            n = sum(1 for *_, d in prof if d == dtype)
+            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, d, _s in prof if d == dtype)
+            tot_fl = sum(f for _, _, f, d, _s in prof if d == dtype)
+            n = sum(1 for _, _, _, d, _s in prof if d == dtype)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             peak = PEAK_BF16_DENSE_TFLOPS if dtype == torch.bfloat16 else 157.3
-            line["roofline"] = {"bound": "mfma", "kernel": f"conv_igemm_kernel<{args.dtype}>", "achieved": ach, "peak": peak,
+            line["roofline"] = {"bound": "mfma", "kernel": f"nlc_conv2d: conv_fast_kernel<{args.dtype},9|1> (+ conv_igemm_kernel for strided shapes)",
+                                "achieved": ach, "peak": peak,
                                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
                                 "avg_launch_us": 1e3 * tot_ms / max(n, 1), "avg_launch_gflop": tot_fl / max(n, 1) / 1e9,
                                 "share_of_wall": tot_ms * 1e-3 / elapsed}
+            if os.environ.get("NLC_BENCH_SHAPES"):
+                agg = {}
+                for e0, e1, f, d, shp in prof:
+                    a = agg.setdefault((str(d), shp), [0, 0.0, 0.0])
+                    a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
+                for (d, shp), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+                    print(f"# conv {d} M={shp[0]} N={shp[1]} taps={shp[2]} Cin={shp[3]} s={shp[4]} ups={shp[5]} C1={shp[6]}: "
+                          f"{cnt} launches, {ms:.1f} ms, {fl / ms / 1e9:.0f} TFLOP/s", file=sys.stderr)
             if res == 256:
                 line["end_to_end_tflops_per_gpu"] = (images / world) * args.timesteps * GF_PER_IMAGE_STEP / 1e3 / elapsed
         if not args.no_cpu_baseline and not args.tiny:

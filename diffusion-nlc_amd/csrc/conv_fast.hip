@@ -1,0 +1,295 @@
+// Fast path of nlc_conv2d: stride-1 3x3 (pad 1) and 1x1 (pad 0) convolutions, the shapes that carry
+// >99 % of the sampling FLOPs.  Same tile geometry and LDS image as conv_igemm.hip (128x128 tile,
+// 4 waves x (4x4) 16x16 MFMA tiles, 128-byte k-blocks, XOR-swizzled rows) but
+//   * global -> LDS staging by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass;
+//     the swizzle is applied on the per-lane SOURCE address (the DMA destination is lane-linear) and
+//     out-of-image taps read a zero page, so padding costs nothing.  The DMA is issued from inline
+//     asm: hipcc drains vmcnt(0) in front of every ds_read it cannot prove disjoint from a pending
+//     LDS-DMA (i.e. all of them), which serialises load and compute; here the DMA of k-step k+1 is
+//     invisible to the compiler, flies under the MFMAs of step k and is retired by ONE hand-placed
+//     s_waitcnt vmcnt(0) in front of the step's barrier (every wave waits for its own DMA, then the
+//     barrier publishes all of them - cdna_hip_programming.md §5.7 item 1);
+//   * the tap loop is fully unrolled inside the channel-block loop: per-row input pixel indices and
+//     validity bits for all taps are computed once per tile, a k-step's address work is one
+//     multiply-add per row;
+//   * the epilogue goes through LDS: bias / embedding / residual / scale / activation are applied
+//     with row-contiguous 16-byte residual loads and output stores instead of 2-byte scatters.
+#include "common.h"
+#include "conv_params.h"
+
+namespace {
+
+__device__ uint4 g_zero_page[8];      // 128 zero bytes: source of every out-of-image / out-of-channel chunk
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_raw> {
+    static constexpr int KBE = KB_BYTES / 2;
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KBE = KB_BYTES / 4;
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * KB_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// One LDS-DMA wave-instruction: lane l's 16 bytes at gptr land at LDS byte address lds_base + 16*l.
+// lds_base must be wave-uniform (it goes through M0, saved and restored around the instruction).
+__device__ __forceinline__ void glds16(const void* gptr, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gptr), "s"(lds_base)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+constexpr int EPI_LD = BN + 4;        // f32 row stride of the epilogue staging image (528 B: conflict-free, 16-B aligned)
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PER = ElemTraits<T>::kPerChunk;
+    constexpr int KBE = Mma<T>::KBE;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int KW = TAPS == 9 ? 3 : 1;
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+
+    const int nblk = p.MT * p.NT;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lr = tid >> 3;                            // LDS row (mod 32) this lane's DMA lands in
+    const int gc = (tid & 7) ^ ((lr >> 1) & 7);         // global 16-byte chunk it fetches (source-side swizzle)
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);   // LDS byte address of smem
+
+    const int HWo = p.Hout * p.Wout;
+    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
+    const int ncb = p.Cin_pad / KBE;
+
+    // ---- per-row tap tables: input pixel index (within the whole tensor) and validity bit per tap
+    int pix[4][TAPS];
+    unsigned vmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lr + 32 * i;
+        vmask[i] = 0;
+        int b = 0, oy = 0, ox = 0;
+        const bool mv = m < p.M;
+        if (mv) { b = m / HWo; const int rem = m - b * HWo; oy = rem / p.Wout; ox = rem - oy * p.Wout; }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            int iy = oy + t / KW - PAD, ix = ox + t % KW - PAD;
+            const bool ok = mv && iy >= 0 && iy < HL && ix >= 0 && ix < WL;
+            if (p.ups) { iy >>= 1; ix >>= 1; }
+            pix[i][t] = ok ? (b * p.Hin + iy) * p.Win + ix : 0;
+            vmask[i] |= (ok ? 1u : 0u) << t;
+        }
+    }
+    const int64_t wrow = (int64_t)TAPS * p.Cin_pad * ES;
+    const char* wbase = p.w + (int64_t)(n0 + lr) * wrow + gc * PER * ES;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // issue the LDS-DMA of k-step (cb, tap) into `stage` (8 wave-instructions per wave: 4 A, 4 B)
+    auto stage_step = [&](int stage, int cb, auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        const unsigned a_base = lds0 + stage * STAGE_BYTES + wave * 8 * KB_BYTES;
+        const unsigned b_base = a_base + BM * KB_BYTES;
+        const int cch = cb * KBE + gc * PER;
+        const char* src; int C, ch;
+        if (cch < p.C0) { src = p.x0; C = p.C0; ch = cch; } else { src = p.x1; C = p.C1; ch = cch - p.C0; }
+        const bool cvalid = cch < p.Ctot;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = cvalid && ((vmask[i] >> tap) & 1u);
+            const char* ptr = ok ? src + ((int64_t)pix[i][tap] * C + ch) * ES : zero;
+            glds16(ptr, a_base + i * 32 * KB_BYTES);
+        }
+        const char* wb = wbase + ((int64_t)tap * p.Cin_pad + cb * KBE) * ES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(wb + (int64_t)i * 32 * wrow, b_base + i * 32 * KB_BYTES);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int stage) {
+        const char* As = smem + stage * STAGE_BYTES;
+        const char* Bs = As + BM * KB_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[4], fb[4];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, chunk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, chunk));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    // ---- main loop: k-step (cb, tap), taps innermost and unrolled.  Per step: issue the DMA of the
+    //      next step into the other stage, compute this stage, wait for the own DMA, barrier.
+    //      WAR safety: the stage being refilled was last read in the previous step, whose trailing
+    //      barrier every wave has passed.
+    stage_step(0, 0, std::integral_constant<int, 0>{});
+    dma_wait_all();
+    __syncthreads();
+    int kt = 0;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const bool last_cb = cb + 1 == ncb;
+        auto body = [&](auto tap_c) {
+            constexpr int tap = decltype(tap_c)::value;
+            const int cur = kt & 1;
+            if constexpr (tap + 1 < TAPS) stage_step(cur ^ 1, cb, std::integral_constant<int, tap + 1>{});
+            else { if (!last_cb) stage_step(cur ^ 1, cb + 1, std::integral_constant<int, 0>{}); }
+            compute(cur);
+            dma_wait_all();
+            __syncthreads();
+            ++kt;
+        };
+        body(std::integral_constant<int, 0>{});
+        if constexpr (TAPS == 9) {
+            body(std::integral_constant<int, 1>{}); body(std::integral_constant<int, 2>{});
+            body(std::integral_constant<int, 3>{}); body(std::integral_constant<int, 4>{});
+            body(std::integral_constant<int, 5>{}); body(std::integral_constant<int, 6>{});
+            body(std::integral_constant<int, 7>{}); body(std::integral_constant<int, 8>{});
+        }
+    }
+
+    // ---- epilogue
+    if (p.out_mode != NLC_OUT_NHWC) {          // NCHW f32 (last layer only): direct stores
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + wm * 64 + i * 16 + fq * 4 + reg;
+                if (m >= p.M) continue;
+                const int b = m / HWo, rem = m - b * HWo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + fr;
+                    if (n >= p.Cout) continue;
+                    float v = acc[i][j][reg];
+                    if (p.bias) v += p.bias[n];
+                    if (p.emb) v += p.emb[(int64_t)b * p.emb_stride + n];
+                    if (p.res) v += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n);
+                    v = apply_act(v * p.out_scale, p.act);
+                    reinterpret_cast<float*>(p.out)[((int64_t)b * p.Cout + n) * HWo + rem] = v;
+                }
+            }
+        return;
+    }
+    // NHWC: two 64-row halves through an f32 LDS image [64][EPI_LD] (33 KiB; both stages are free now)
+    float* epi = reinterpret_cast<float*>(smem);
+    const bool vec_ok = (p.Cout % PER) == 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        epi[(i * 16 + fq * 4 + reg) * EPI_LD + wn * 64 + j * 16 + fr] = acc[i][j][reg];
+        }
+        __syncthreads();
+        // 64 rows x (128/PER) chunks, one chunk (PER columns of one row) per thread per iteration
+        constexpr int CPR = BN / PER;
+        for (int e = tid; e < 64 * CPR; e += NTHREADS) {
+            const int row = e / CPR, cc = e - row * CPR;
+            const int m = m0 + half * 64 + row;
+            const int n = n0 + cc * PER;
+            if (m >= p.M || n >= p.Cout) continue;
+            float v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(epi + row * EPI_LD + cc * PER + k);
+                v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+            }
+            const int b = m / HWo;
+            const bool full = vec_ok && (n + PER <= p.Cout);
+            float r[PER];
+            if (p.res) {
+                const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
+                if (full) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rp), r);
+                else {
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) r[k] = (n + k < p.Cout) ? ElemTraits<T>::load(rp + k) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int nn = n + k;
+                float x = v[k];
+                if (nn < p.Cout) {
+                    if (p.bias) x += p.bias[nn];
+                    if (p.emb) x += p.emb[(int64_t)b * p.emb_stride + nn];
+                    if (p.res) x += r[k];
+                    x = apply_act(x * p.out_scale, p.act);
+                }
+                v[k] = x;
+            }
+            T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
+            if (full) *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
+            else {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS>
+int launch_fast(const KParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_fast_kernel<T, TAPS>), dim3(p.MT * p.NT), dim3(NTHREADS), LDS_BYTES, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { nlc_set_error("nlc_conv2d(fast): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
+    return NLC_OK;
+}
+
+}  // namespace
+
+// returns NLC_EUNSUPPORTED when the shape is not one the fast path handles (caller falls back)
+int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream) {
+    const bool k3 = p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1;
+    const bool k1 = p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0;
+    if (p.stride != 1 || !(k3 || k1)) return NLC_EUNSUPPORTED;
+    if ((int64_t)p.B * p.Hin * p.Win >= (1ll << 31)) return NLC_EUNSUPPORTED;
+    if (dtype == NLC_BF16) return k3 ? launch_fast<bf16_raw, 9>(p, stream) : launch_fast<bf16_raw, 1>(p, stream);
+    return k3 ? launch_fast<float, 9>(p, stream) : launch_fast<float, 1>(p, stream);
+}

@@ -20,27 +20,10 @@
 //   f32 : v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) - 4 MFMAs per 16-byte fragment pair,
 //         with the same k permutation on both operands.
 #include "common.h"
+#include "conv_params.h"
+#include <stdlib.h>
 
 namespace {
-
-constexpr int BM = 128;
-constexpr int BN = 128;
-constexpr int KB_BYTES = 128;
-constexpr int NTHREADS = 256;
-constexpr int STAGE_BYTES = (BM + BN) * KB_BYTES;   // 32 KiB
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;          // 64 KiB
-
-struct KParams {
-    const char* x0; const char* x1;
-    int C0, C1, Ctot;
-    int B, Hin, Win, Hout, Wout, Cout;
-    int KH, KW, stride, pad_t, pad_l, ups;
-    const char* w; int Cin_pad, Cout_pad;
-    const float* bias; const float* emb; int emb_stride;
-    const char* res; float out_scale; int act;
-    char* out; int out_mode;
-    int M, MT, NT;
-};
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_raw> {
@@ -291,6 +274,14 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act;
     p.out = (char*)d->out; p.out_mode = d->out_mode;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
+    // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
+    // odd kernels, cropped outputs) the generic gather kernel.  NLC_CONV_GENERIC=1 forces the latter (A/B runs).
+    static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
+    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
+    if (!force_generic && p.Hout == HL && p.Wout == WL) {
+        const int rc = nlc_conv_fast_dispatch(p, dtype, (hipStream_t)stream);
+        if (rc != NLC_EUNSUPPORTED) return rc;
+    }
     if (dtype == NLC_BF16) return launch<bf16_raw>(p, (hipStream_t)stream);
     return launch<float>(p, (hipStream_t)stream);
 }

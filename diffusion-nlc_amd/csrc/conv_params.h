@@ -1,0 +1,27 @@
+// Tile geometry and kernel parameter block shared by the generic (conv_igemm.hip) and the fast
+// (conv_fast.hip) implicit-GEMM convolution kernels.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+constexpr int BM = 128;                              // output pixels per tile
+constexpr int BN = 128;                              // output channels per tile
+constexpr int KB_BYTES = 128;                        // bytes of K per row per k-step
+constexpr int NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM + BN) * KB_BYTES;    // 32 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // 64 KiB -> 2 workgroups per CU
+
+struct KParams {
+    const char* x0; const char* x1;
+    int C0, C1, Ctot;
+    int B, Hin, Win, Hout, Wout, Cout;
+    int KH, KW, stride, pad_t, pad_l, ups;
+    const char* w; int Cin_pad, Cout_pad;
+    const float* bias; const float* emb; int emb_stride;
+    const char* res; float out_scale; int act;
+    char* out; int out_mode;
+    int M, MT, NT;
+};
+
+// conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)
+int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);

@@ -163,7 +163,8 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         e0.record()
         check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
         e1.record()
-        prof.append((e0, e1, 2.0 * B * Hout * Wout * pw.Cout * pw.KH * pw.KW * pw.Cin, dt))
+        prof.append((e0, e1, 2.0 * B * Hout * Wout * pw.Cout * pw.KH * pw.KW * pw.Cin, dt,
+                     (B * Hout * Wout, pw.Cout, pw.KH * pw.KW, pw.Cin, stride, int(upsample2x), C1)))
     else:
         check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
     if linear and not out_nchw_f32:
