@@ -88,14 +88,20 @@ def cpu_baseline(cfg, max_seconds=240.0):
                         norm_max=440.0 * res / 256, clip_fn="dynamic")
     z = torch.randn((1, 3, res, res), generator=torch.Generator().manual_seed(1234))
     xt = z / (1 / (s.sampling_sigmas[0] ** 2 + 1)).sqrt()
-    t0 = time.perf_counter()
+    def one_timestep(x, ind):
+        eps, lv, st, sp = o.get_denoise_vector(x, s.timesteps[ind], s.sampling_sigmas[ind], s.sampling_sigmas[ind + 1], "pred", True, True)
+        x0 = o.clip(s.pred_xstart(x, eps, st))
+        return s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=x, log_variance=lv)
+
+    # bounded sample: keep stepping the real trajectory until ~15 s of CPU work (at most 20 of the 50 timesteps)
+    n, t0 = 0, time.perf_counter()
     with torch.no_grad():
-        eps, lv, st, sp = o.get_denoise_vector(xt, s.timesteps[0], s.sampling_sigmas[0], s.sampling_sigmas[1], "pred", True, True)
-        x0 = o.clip(s.pred_xstart(xt, eps, st))
-        s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=xt, log_variance=lv)
-    dt = time.perf_counter() - t0
+        while n < 20 and (n == 0 or time.perf_counter() - t0 < 15.0):
+            xt = one_timestep(xt, n)
+            n += 1
+    dt = (time.perf_counter() - t0) / n
     return {"value": 1.0 / (50.0 * dt), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 DDIM+NLC timestep of ADM-{res} at B=1 in f32 on the host ({dt:.1f} s), extrapolated x50 timesteps"}
+            "sample": f"{n} DDIM+NLC timestep(s) of ADM-{res} at B=1 in f32 on the host ({dt:.2f} s each), extrapolated to 50 timesteps"}
 
 
 def main():
