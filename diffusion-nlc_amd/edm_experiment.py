@@ -1,0 +1,225 @@
+"""EDM / Heun + NLC sampler on the device (drop-in for EDMImageExperiment, src/experiments.py:756-961).
+
+As in the reference the sampler state and eps are FLOAT64 and the network runs in float32
+(:860,872,789-802).  All B x D work is HIP kernels (csrc/edm.hip + the networks); the per-sample sigma
+bookkeeping (a handful of [B]-sized f64 values per evaluation) is plain tensor algebra on device
+tensors so nothing syncs with the host inside the loop.
+
+    per evaluation   nlc_cast_f64_f32(x)                         x.to(float32)                    (:778,789)
+                     [nlc_row_sumsq_f64]                         refine_prior_sigma norm          (:808-815)
+                     nlc_edm_scalars                             c_in, c_noise, c_skip, c_out     (:790-797)
+                     SongUNet.encode -> SigmaModel (HIP nets)    NLC residual r                   (:822-828)
+                     SongUNet.forward (input scaled by c_in in the first conv)                    (:799)
+                     nlc_edm_eps                                 denoised, eps = (x-D)/sigma      (:801,836-840)
+                     [nlc_row_sumsq_f64 + nlc_f64_lincomb]       normalize(eps)                   (:841-842)
+    per step         nlc_f64_lincomb x4-6                        eps rescale, Euler, mix, Heun    (:884-917)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _ext, ops
+from ._ext import NlcError, check
+from .experiments import ImageExperiment, StackedRandomGenerator
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def cast_f64_f32(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(_ext.load().nlc_cast_f64_f32(x.data_ptr(), out.data_ptr(), x.numel(), _s()), "nlc_cast_f64_f32")
+    return out
+
+
+def row_sumsq_f64(x: torch.Tensor) -> torch.Tensor:
+    B = x.shape[0]
+    out = torch.empty(B, device=x.device, dtype=torch.float64)
+    check(_ext.load().nlc_row_sumsq_f64(x.data_ptr(), out.data_ptr(), B, x.numel() // B, _s()), "nlc_row_sumsq_f64")
+    return out
+
+
+def lincomb(x: torch.Tensor, ca: torch.Tensor, y: Optional[torch.Tensor] = None, cb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ca[b]*x (+ cb[b]*y) in f64; coefficients are [B] f64 device tensors."""
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    ca = ca.to(torch.float64).contiguous()
+    if cb is not None:
+        cb = cb.to(torch.float64).contiguous()
+    check(_ext.load().nlc_f64_lincomb(x.data_ptr(), ca.data_ptr(), None if y is None else y.data_ptr(),
+                                      None if cb is None else cb.data_ptr(), out.data_ptr(), B, x.numel() // B, _s()),
+          "nlc_f64_lincomb")
+    return out
+
+
+class EDMImageExperiment(ImageExperiment):
+    def __init__(self, model, scheduler, batch_size=64, data_shape=(3, 32, 32), seed=0, device="cuda:0", save_folder="./",
+                 dist_train=False, time_shift=0, sigma_min=0.002, sigma_max=80, rho=7, S_churn=0, S_min=0,
+                 S_max=float("inf"), S_noise=1, sigma_data=0.5, P_mean=-1.2, P_std=1.2, num_timesteps=18):
+        super().__init__(model=model, scheduler=scheduler, batch_size=batch_size, data_shape=data_shape, seed=seed,
+                         device=device, save_folder=save_folder, dist_train=dist_train, time_shift=time_shift)
+        self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
+        self.S_churn, self.S_min, self.S_max, self.S_noise = S_churn, S_min, S_max, S_noise
+        self.sigma_data, self.P_mean, self.P_std = sigma_data, P_mean, P_std
+        self.num_timesteps = num_timesteps
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _per_sample(self, v, B):
+        v = torch.as_tensor(v, dtype=torch.float64, device=self.device).reshape(-1)
+        return v.expand(B).contiguous() if v.numel() == 1 else v.contiguous()
+
+    def _scalars(self, sigma):
+        B = sigma.shape[0]
+        f = lambda: torch.empty(B, device=self.device, dtype=torch.float32)
+        c_in, c_noise, c_skip, c_out = f(), f(), f(), f()
+        check(_ext.load().nlc_edm_scalars(sigma.data_ptr(), float(self.sigma_data), c_in.data_ptr(), c_noise.data_ptr(),
+                                          c_skip.data_ptr(), c_out.data_ptr(), B, _s()), "nlc_edm_scalars")
+        return c_in, c_noise, c_skip, c_out
+
+    def encode_edm(self, xt, sigma):
+        """:777-786 (returns NCHW f32 like the reference)."""
+        xt = xt.to(self.device, torch.float64).contiguous()
+        c_in, c_noise, _, _ = self._scalars(self._per_sample(sigma, xt.shape[0]))
+        return self.model.run(cast_f64_f32(xt), c_noise, mode="encode", in_scale=c_in)
+
+    def pred_edm(self, xt, sigma):
+        """:788-802"""
+        xt = xt.to(self.device, torch.float64).contiguous()
+        B = xt.shape[0]
+        sig = self._per_sample(sigma, B)
+        c_in, c_noise, c_skip, c_out = self._scalars(sig)
+        x32 = cast_f64_f32(xt)
+        F = self.model.run(x32, c_noise, mode="forward", in_scale=c_in)
+        eps = torch.empty_like(xt)
+        den = torch.empty_like(xt)
+        check(_ext.load().nlc_edm_eps(xt.data_ptr(), x32.data_ptr(), F.data_ptr(), c_skip.data_ptr(), c_out.data_ptr(),
+                                      sig.data_ptr(), eps.data_ptr(), den.data_ptr(), B, xt.numel() // B, _s()), "nlc_edm_eps")
+        return den.float()
+
+    @torch.no_grad()
+    def get_denoise_vector(self, xt, sigma_t, sigma_prev, style="base", norm_eps=False, refine_prior_sigma=False):
+        """:804-843.  xt: f64 [B,C,H,W] on the device; sigma_t / sigma_prev: scalars or [B]-like.
+        Returns (eps f64, denoised f64, sigma_t [B,1,1,1] f64, sigma_prev [B,1,1,1] f64)."""
+        B = xt.shape[0]
+        D = xt.numel() // B
+        sig_t, sig_p = self._per_sample(sigma_t, B), self._per_sample(sigma_prev, B)
+        sig_orig = sig_t
+        if refine_prior_sigma:
+            norm_x = row_sumsq_f64(xt).sqrt() / math.sqrt(self.dim)
+            min_dist = torch.clamp(norm_x - self.norm_max, min=0)
+            sig_t = torch.minimum(torch.maximum(sig_t, min_dist), norm_x + self.norm_min)     # torch.clamp(min=, max=) order
+        x32 = cast_f64_f32(xt)
+        if "pred" in style:
+            if self.sigma_model is None:
+                raise NlcError("style '%s' needs a sigma model (set_model)" % style)
+            c_in, c_noise, _, _ = self._scalars(sig_t)
+            feat = self.model.run(x32, c_noise, mode="encode", in_scale=c_in, feat_nhwc=True)
+            r = self.sigma_model.run_nhwc(feat)                               # f32 [B]
+            dist_hat = sig_t * (1 + r)                                        # f64 * f32 -> f64, as in the reference
+            dist_prev_hat = dist_hat * (sig_p / sig_t)
+            sig_t = dist_hat
+            if style == "pred":
+                sig_p = dist_prev_hat
+        sig_div = sig_orig if style == "pred_sigma" else sig_t
+        sig_div = sig_div.contiguous()
+        c_in, c_noise, c_skip, c_out = self._scalars(sig_div)
+        F = self.model.run(x32, c_noise, mode="forward", in_scale=c_in)
+        eps, den = torch.empty_like(xt), torch.empty_like(xt)
+        check(_ext.load().nlc_edm_eps(xt.data_ptr(), x32.data_ptr(), F.data_ptr(), c_skip.data_ptr(), c_out.data_ptr(),
+                                      sig_div.data_ptr(), eps.data_ptr(), den.data_ptr(), B, D, _s()), "nlc_edm_eps")
+        if norm_eps:
+            eps = self._normalize(eps)
+        return eps, den, sig_t.view(B, 1, 1, 1), sig_p.view(B, 1, 1, 1)
+
+    def _normalize(self, x):
+        """utils.normalize on the f64 tensor (:841-842,908-909)."""
+        denom = torch.clamp(row_sumsq_f64(x).sqrt(), min=1e-12)
+        return lincomb(x, math.sqrt(self.dim) / denom)
+
+    @torch.no_grad()
+    def edm_sampler(self, shape, gen=None, style="base,base", norm_eps="000", refine_prior_sigma=False, num_steps=None,
+                    sigma_scheduler="EDM", eps_ratio=0.5, eps_scale=1.0, use_second_order=True, latents=None):
+        """:846-918.  ``latents`` (optional, host or device N(0,1)) replaces ``gen.randn(shape)``."""
+        norm_e, norm_combine = bool(int(norm_eps[0])), bool(int(norm_eps[1]))
+        style_t, style_next = style.split(",")
+        n = self.num_timesteps if num_steps is None else num_steps
+        if latents is None:
+            latents = gen.randn(shape, device=self.device)
+        latents = latents.to(self.device)
+        B = latents.shape[0]
+        idx = torch.arange(n, dtype=torch.float64)
+        if sigma_scheduler == "EDM":
+            steps = (self.sigma_max ** (1 / self.rho) + idx / (n - 1) * (self.sigma_min ** (1 / self.rho) - self.sigma_max ** (1 / self.rho))) ** self.rho
+        elif sigma_scheduler == "Linear":
+            steps = torch.tensor(np.exp(np.linspace(np.log(self.sigma_max), np.log(self.sigma_min), n)))
+        else:
+            raise NotImplementedError
+        steps = torch.cat([torch.as_tensor(steps), torch.zeros_like(steps[:1])])          # host f64 schedule
+        if eps_scale is None:
+            raise NotImplementedError("cosine-similarity eps scaling (eps_scale=None, :912-916) is a SURVEY §8 'next' row (f-3)")
+        one = torch.ones(B, device=self.device, dtype=torch.float64)
+        x_next = lincomb(latents.to(torch.float64).contiguous(), one * float(steps[0]))
+        for i, (s_cur, s_next) in enumerate(zip(steps[:-1], steps[1:])):
+            x_cur = x_next
+            s_cur, s_next0 = float(s_cur), float(s_next)
+            gamma = min(self.S_churn / n, np.sqrt(2) - 1) if self.S_min <= s_cur <= self.S_max else 0
+            s_hat0 = s_cur + gamma * s_cur
+            if gamma > 0:                                                      # churn noise, host-drawn (:880)
+                z = torch.randn(x_cur.shape, dtype=torch.float64).to(self.device)
+                x_hat = lincomb(x_cur, one, z, one * (math.sqrt(s_hat0 ** 2 - s_cur ** 2) * self.S_noise))
+            else:
+                x_hat = x_cur                                                  # + 0 * randn_like: exact no-op
+            eps, _, s_hat, s_nxt = self.get_denoise_vector(x_hat, s_hat0, s_next0, style=style_t, norm_eps=norm_e,
+                                                           refine_prior_sigma=refine_prior_sigma)
+            s_hat, s_nxt = s_hat.view(B), s_nxt.view(B)
+            eps = lincomb(eps, s_hat / s_hat0)                                 # eps * (sigma_hat / sigma_hat0)  (:884)
+            if "pred_partial" in style_t:
+                s_nxt = one * s_next0
+            if style_t == "pred_partial":
+                x_next = lincomb(x_hat, one, eps, s_nxt - s_hat0)
+            else:
+                x_next = lincomb(x_hat, one, eps, s_nxt - s_hat)
+            if style_t == "pred_partial3":
+                s_hat = one * s_hat0
+            if i < n - 1 and use_second_order:
+                s_nxt_in = s_nxt
+                eps_next, _, s_nxt, _ = self.get_denoise_vector(x_next, s_nxt_in, s_nxt_in * 0, style=style_next,
+                                                                norm_eps=norm_e, refine_prior_sigma=refine_prior_sigma)
+                s_nxt = s_nxt.view(B)
+                eps_next = lincomb(eps_next, s_nxt / s_next0)                 # (:904)
+                if "pred_partial" in style_next:
+                    s_nxt = one * s_next0
+                new_eps = lincomb(eps, one * eps_ratio, eps_next, one * (1 - eps_ratio))
+                if norm_combine:
+                    new_eps = self._normalize(new_eps)
+                new_eps = lincomb(new_eps, one / eps_scale)
+                x_next = lincomb(x_hat, one, new_eps, s_nxt - s_hat)
+        return x_next
+
+    @torch.no_grad()
+    def evaluate_edm(self, n_samples, images_dir=None, gen=None, style="base,base", norm_eps="000", refine_prior_sigma=False,
+                     microbatch=-1, sigma_scheduler="EDM", eps_ratio=0.5, eps_scale=1.0, use_second_order=True, save_fn=None):
+        """:922-961: per-batch host generators seeded 0..n-1 (StackedRandomGenerator), samples mapped to [0,1].
+        PNG writing / FID are optional side effects: ``save_fn(sample01, batch_index)`` if given."""
+        batch_size = microbatch if microbatch > 0 else self.batch_size
+        if n_samples % batch_size:
+            raise ValueError("n_samples must be a multiple of batch_size (the reference asserts this at :77, SURVEY.md §9)")
+        seeds = torch.arange(n_samples).tensor_split(n_samples // batch_size)
+        outs = []
+        for i, sd in enumerate(seeds):
+            g = StackedRandomGenerator(self.device, sd)
+            x = self.edm_sampler(shape=(batch_size,) + self.data_shape, gen=g, style=style, norm_eps=norm_eps,
+                                 refine_prior_sigma=refine_prior_sigma, sigma_scheduler=sigma_scheduler, eps_ratio=eps_ratio,
+                                 eps_scale=eps_scale, use_second_order=use_second_order)
+            sample = x.add(1).div(2).clamp(0, 1)
+            if save_fn is not None:
+                save_fn(sample, i)
+            outs.append(sample)
+        fid = self.fid_fn(images_dir) if (self.fid_fn is not None and images_dir) else float("nan")
+        return {"fid": fid}, torch.cat(outs)

@@ -316,3 +316,6 @@ class ImageExperiment(ExperimentDiffusion):
                  dist_train=False, time_shift=0):
         super().__init__(model=model, scheduler=scheduler, batch_size=batch_size, data_shape=data_shape,
                          save_folder=save_folder, seed=seed, device=device, dist_train=dist_train, time_shift=time_shift)
+
+
+from .edm_experiment import EDMImageExperiment  # noqa: E402,F401  (bottom import: edm_experiment needs ImageExperiment)

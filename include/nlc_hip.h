@@ -211,6 +211,27 @@ int nlc_sched_step(const nlc_sched_desc* d, int* nan_flag, void* stream);
 int nlc_scale_rows(const float* x, const float* scale /*[B]*/, float scalar, float* out,
                    int B, int64_t D, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * EDM / Heun + NLC sampler state (src/experiments.py:777-918): the state and eps are FLOAT64,
+ * the network runs in float32, exactly as in the reference (:860,872,789-802).
+ * ---------------------------------------------------------------------------------- */
+/* out[i] = (float)x[i]                       xt.to(torch.float32), :778,789 */
+int nlc_cast_f64_f32(const double* x, float* out, int64_t n, void* stream);
+/* sumsq[b] = sum_d x[b,d]^2 in f64            vector_norm on the f64 state, :808,842 */
+int nlc_row_sumsq_f64(const double* x, double* sumsq, int B, int64_t D, void* stream);
+/* preconditioning scalars from sigma[b] cast to f32 (:790-797):
+ *   c_skip = sd^2/(s^2+sd^2), c_out = s*sd/sqrt(s^2+sd^2), c_in = 1/sqrt(sd^2+s^2), c_noise = ln(s)/4 */
+int nlc_edm_scalars(const double* sigma, float sigma_data, float* c_in, float* c_noise,
+                    float* c_skip, float* c_out, int B, void* stream);
+/* D_x = c_skip*x32 + c_out*F (f32) ; denoised = (double)D_x ; eps = (x - denoised)/sigma_div[b]  (:801,836-840)
+ * denoised may be NULL. */
+int nlc_edm_eps(const double* x, const float* x32, const float* F, const float* c_skip,
+                const float* c_out, const double* sigma_div, double* eps, double* denoised,
+                int B, int64_t D, void* stream);
+/* out[b,:] = ca[b]*x[b,:] (+ cb[b]*y[b,:])   the Euler / Heun updates, eps mixing and scaling (:884-917) */
+int nlc_f64_lincomb(const double* x, const double* ca, const double* y, const double* cb,
+                    double* out, int B, int64_t D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

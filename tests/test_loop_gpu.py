@@ -75,3 +75,34 @@ def test_loop_without_logging_is_identical():
     x1, _ = run_hip_loop(g, return_log=True)
     x2, logs = run_hip_loop(g, return_log=False)
     assert torch.equal(x1, x2) and logs[1] == []
+
+
+@pytest.mark.parametrize("name", ["loop_edm_pred", "loop_edm_base", "loop_edm_euler"])
+def test_f32_edm_sampler_matches_reference(name):
+    """EDM / Heun + NLC (float64 state, float32 network) vs the reference's own edm_sampler output."""
+    from diffusion_nlc_amd.experiments import EDMImageExperiment
+    g = load_npz(name)
+    c = g["cfg"]
+    eps, sig = _models("edm_tiny", torch.float32)
+    exp = EDMImageExperiment(eps, None, batch_size=2, data_shape=(3, 32, 32), seed=0, device="cuda:0", num_timesteps=c["steps"])
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 54.63)
+    x = exp.edm_sampler(shape=(2, 3, 32, 32), latents=g["latents"], style=c["style"], norm_eps=c["norm_eps"],
+                        eps_ratio=0.5, eps_scale=1.0, use_second_order=c["second"])
+    assert x.dtype == torch.float64
+    ex = max_err(x.cpu(), g["x"])
+    print(f"{name}: f32-net / f64-state L-inf {ex:.2e}")
+    assert ex < 1e-3
+
+
+def test_edm_evaluate_runs_and_is_deterministic():
+    from diffusion_nlc_amd.experiments import EDMImageExperiment
+    eps, sig = _models("edm_tiny", torch.float32)
+    exp = EDMImageExperiment(eps, None, batch_size=2, data_shape=(3, 32, 32), seed=0, device="cuda:0", num_timesteps=4)
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 54.63)
+    _, a = exp.evaluate_edm(4, style="pred_partial,pred", norm_eps="000")
+    _, b = exp.evaluate_edm(4, style="pred_partial,pred", norm_eps="000")
+    assert a.shape == (4, 3, 32, 32) and torch.equal(a, b) and a.min() >= 0 and a.max() <= 1
+    with pytest.raises(ValueError):
+        exp.evaluate_edm(3)

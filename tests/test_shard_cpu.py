@@ -22,7 +22,7 @@ def _worker(rank, world, port, n_batches, q):
     r, w, _ = shard.init_from_env("gloo")
     out = shard.sample_sharded(_fake_sampler, SHAPE, n_batches, seed=1234, world=w, rank=r, device="cpu")
     if r == 0:
-        q.put(out)
+        q.put(out.numpy())          # by value: torch tensors travel by fd and the producer may exit first
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,7 +44,7 @@ def test_two_ranks_equal_single_process(n_batches):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_batches, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = torch.from_numpy(q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
