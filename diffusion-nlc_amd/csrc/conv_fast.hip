@@ -168,9 +168,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
         auto body = [&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
             const int cur = kt & 1;
-            if constexpr (tap + 1 < TAPS) stage_step(cur ^ 1, cb, std::integral_constant<int, tap + 1>{});
-            else { if (!last_cb) stage_step(cur ^ 1, cb + 1, std::integral_constant<int, 0>{}); }
-            compute(cur);
+            if (p.abl != 1) {
+                if constexpr (tap + 1 < TAPS) stage_step(cur ^ 1, cb, std::integral_constant<int, tap + 1>{});
+                else { if (!last_cb) stage_step(cur ^ 1, cb + 1, std::integral_constant<int, 0>{}); }
+            }
+            if (p.abl != 2) compute(cur);
             dma_wait_all();
             __syncthreads();
             ++kt;

@@ -274,12 +274,16 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act;
     p.out = (char*)d->out; p.out_mode = d->out_mode;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
+    static const int abl = getenv("NLC_CONV_ABL") ? atoi(getenv("NLC_CONV_ABL")) : 0;
+    p.abl = abl;
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  NLC_CONV_GENERIC=1 forces the latter (A/B runs).
     static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     if (!force_generic && p.Hout == HL && p.Wout == WL) {
-        const int rc = nlc_conv_fast_dispatch(p, dtype, (hipStream_t)stream);
+        int rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
+        if (rc != NLC_EUNSUPPORTED) return rc;
+        rc = nlc_conv_fast_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
     }
     if (dtype == NLC_BF16) return launch<bf16_raw>(p, (hipStream_t)stream);

@@ -21,7 +21,10 @@ struct KParams {
     const char* res; float out_scale; int act;
     char* out; int out_mode;
     int M, MT, NT;
+    int abl;        // timing-only ablation (NLC_CONV_ABL): 1 = no staging in the k-loop, 2 = no MFMA work; results are wrong
 };
 
 // conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);
+// conv_halo.hip: 3x3 with the input halo resident in LDS; same return convention
+int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream);

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of nlc_conv2d on the ADM-256 hot shapes (B=16), HIP events on the launch stream.
+
+    python tools/conv_bench.py [--reps 20]
+    NLC_CONV_ABL=1|2 python tools/conv_bench.py      # timing-only ablations (no staging / no MFMA)
+"""
+import argparse
+import math
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from diffusion_nlc_amd import ops  # noqa: E402
+
+SHAPES = [  # (H, Cin, Cout, k, note)
+    (256, 256, 256, 3, "256->256 @256^2 (31% of FLOPs)"),
+    (256, 512, 256, 3, "512->256 @256^2"),
+    (128, 256, 256, 3, "256->256 @128^2"),
+    (64, 512, 512, 3, "512->512 @64^2"),
+    (32, 512, 512, 3, "512->512 @32^2"),
+    (16, 1024, 1024, 3, "1024->1024 @16^2"),
+    (8, 1024, 1024, 3, "1024->1024 @8^2"),
+    (256, 768, 256, 1, "1x1 768->256 @256^2"),
+    (32, 512, 1536, 1, "qkv 512->1536 @32^2"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    for H, cin, cout, k, note in SHAPES:
+        x = torch.randn(args.batch, H, H, cin, device=dev).to(dt)
+        w = torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)
+        pw = ops.pack_conv(w, torch.zeros(cout), dt, dev)
+        for _ in range(3):
+            ops.conv2d(x, pw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            ops.conv2d(x, pw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        fl = 2.0 * args.batch * H * H * cout * cin * k * k
+        print(f"{note:32s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
