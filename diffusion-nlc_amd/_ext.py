@@ -12,7 +12,7 @@ import subprocess
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libnlc_hip.so"
+LIB_PATH = Path(os.environ.get("NLC_HIP_LIB", _HERE / "libnlc_hip.so"))     # override: kernel A/B experiments only
 BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
 
 NLC_F32, NLC_BF16 = 0, 1

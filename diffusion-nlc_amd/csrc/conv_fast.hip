@@ -225,47 +225,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
                         epi[(i * 16 + fq * 4 + reg) * EPI_LD + wn * 64 + j * 16 + fr] = acc[i][j][reg];
         }
         __syncthreads();
-        // 64 rows x (128/PER) chunks, one chunk (PER columns of one row) per thread per iteration
+        // each thread owns ONE 16-byte column chunk (cc) for 64*CPR/NTHREADS rows: per-column terms are loaded
+        // once, the row loop is unrolled so several rows' LDS reads / residual loads / stores are in flight together
         constexpr int CPR = BN / PER;
-        for (int e = tid; e < 64 * CPR; e += NTHREADS) {
-            const int row = e / CPR, cc = e - row * CPR;
-            const int m = m0 + half * 64 + row;
-            const int n = n0 + cc * PER;
-            if (m >= p.M || n >= p.Cout) continue;
-            float v[PER];
-#pragma unroll
-            for (int k = 0; k < PER; k += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(epi + row * EPI_LD + cc * PER + k);
-                v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
-            }
-            const int b = m / HWo;
+        constexpr int RSTEP = NTHREADS / CPR, NIT = 64 / RSTEP;
+        const int cc = tid % CPR, row0 = tid / CPR;
+        const int n = n0 + cc * PER;
+        if (n < p.Cout) {
             const bool full = vec_ok && (n + PER <= p.Cout);
-            float r[PER];
-            if (p.res) {
-                const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
-                if (full) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rp), r);
+            float cbias[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) cbias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = row0 + it * RSTEP;
+                const int m = m0 + half * 64 + row;
+                if (m >= p.M) continue;
+                float v[PER];
+#pragma unroll
+                for (int k = 0; k < PER; k += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(epi + row * EPI_LD + cc * PER + k);
+                    v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+                }
+                const int b = m / HWo;
+                float r[PER];
+#pragma unroll
+                for (int k = 0; k < PER; ++k) r[k] = 0.f;
+                if (p.res) {
+                    const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
+                    if (full) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rp), r);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < PER; ++k) r[k] = (n + k < p.Cout) ? ElemTraits<T>::load(rp + k) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    float x = v[k];
+                    if (p.bias) x += cbias[k];
+                    if (p.emb) x += (n + k < p.Cout) ? p.emb[(int64_t)b * p.emb_stride + n + k] : 0.f;
+                    if (p.res) x += r[k];
+                    v[k] = apply_act(x * p.out_scale, p.act);
+                }
+                T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
+                if (full) *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
                 else {
 #pragma unroll
-                    for (int k = 0; k < PER; ++k) r[k] = (n + k < p.Cout) ? ElemTraits<T>::load(rp + k) : 0.f;
+                    for (int k = 0; k < PER; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int nn = n + k;
-                float x = v[k];
-                if (nn < p.Cout) {
-                    if (p.bias) x += p.bias[nn];
-                    if (p.emb) x += p.emb[(int64_t)b * p.emb_stride + nn];
-                    if (p.res) x += r[k];
-                    x = apply_act(x * p.out_scale, p.act);
-                }
-                v[k] = x;
-            }
-            T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
-            if (full) *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
-            else {
-#pragma unroll
-                for (int k = 0; k < PER; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
             }
         }
     }

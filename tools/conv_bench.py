@@ -32,7 +32,11 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", type=int, default=-1, help="run only SHAPES[i] (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
+    global SHAPES
+    if args.only >= 0:
+        SHAPES = SHAPES[args.only:args.only + 1]
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     for H, cin, cout, k, note in SHAPES:
