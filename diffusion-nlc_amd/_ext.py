@@ -98,6 +98,8 @@ SIGNATURES = {
     "nlc_edm_scalars": (C.c_int, [_vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "nlc_edm_eps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "nlc_f64_lincomb": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "nlc_inpaint_A": (C.c_int, [_vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
+    "nlc_inpaint_Apinv": (C.c_int, [_vp, _vp, _vp, _i, _i, _i64, _i64, _vp]),
 }
 
 _lib = None

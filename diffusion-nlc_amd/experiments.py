@@ -272,7 +272,14 @@ class ExperimentDiffusion:
                 d.dyn_s = dyn.data_ptr()
             x0_hat = None
             use_constraint = constrain_fn is not None and (free_const_steps <= 0 or ind <= free_const_steps)
-            if use_constraint or (return_log and constrain_fn is not None):
+            fused_mask = use_constraint and not return_log and hasattr(constrain_fn, "mask_chw") and hasattr(constrain_fn, "known")
+            if fused_mask:
+                # inpainting projection x0 - A^+(A x0 - y) == "copy the known pixels": one fused kernel does
+                # clip + projection + x_prev
+                d.mask, d.known = constrain_fn.mask_chw.data_ptr(), constrain_fn.known.data_ptr()
+                ops.sched_step(d, st["nan"])
+                x0_hat = x0
+            elif use_constraint or (return_log and constrain_fn is not None):
                 d.phases = 1                                   # clip only
                 ops.sched_step(d)
                 x0_hat = x0.clone() if return_log else x0

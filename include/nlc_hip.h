@@ -232,6 +232,19 @@ int nlc_edm_eps(const double* x, const float* x32, const float* F, const float* 
 int nlc_f64_lincomb(const double* x, const double* ca, const double* y, const double* cb,
                     double* out, int B, int64_t D, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Inpainting measurement operator (functions/svd_operators.py:324-359, Inpainting.A / A_pinv through
+ * V/Vt/U/Ut/add_zeros at :52-58,68-80) on the NCHW f32 state.  Indices live in the reference's
+ * pixel-interleaved flattening  idx = p*C + c.
+ *   nlc_inpaint_A     : out[b][j] = x[b][c][p]                    kept[j] = p*C + c   (int64, sorted)
+ *   nlc_inpaint_Apinv : out[b][c][p] = inv[p*C+c] >= 0 ? y[b][inv[p*C+c]] : 0        (inv: int32 [HW*C])
+ * The per-step projection x0 <- x0 - A^+(A x0 - y) is the mask/known path of nlc_sched_step.
+ * ---------------------------------------------------------------------------------- */
+int nlc_inpaint_A(const float* x, const int64_t* kept, float* out, int B, int C, int64_t HW,
+                  int64_t nk, void* stream);
+int nlc_inpaint_Apinv(const float* y, const int32_t* inv, float* out, int B, int C, int64_t HW,
+                      int64_t nk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,6 +268,48 @@ def gen_loops(models):
         save(name, latents=lat, x=x, cfg=json.dumps(dict(style=style, second=second, norm_eps=norm + "0", steps=6)))
 
 
+@torch.no_grad()
+def gen_inpaint(models):
+    """Inpainting operator (functions/svd_operators.py) and a constrained denoise_loop (BASELINE config 4, reduced)."""
+    from functools import partial
+    from functions.svd_operators import Inpainting
+    from src.schedulers import get_sampler
+    from src.experiments import ImageExperiment
+    res, C, B = 32, 3, 2
+    g = torch.Generator().manual_seed(11)
+    missing_r = torch.randperm(res * res, generator=g)[: res * res // 2].long() * 3       # constraint_functions.py:230-231
+    missing = torch.cat([missing_r, missing_r + 1, missing_r + 2], dim=0)
+    op = Inpainting(C, res, missing, "cpu")
+    x_gt = torch.rand(B, C, res, res, generator=g) * 2 - 1
+    y = op.A(x_gt)
+    apy = op.A_pinv(y).view(B, C, res, res)
+
+    def affine_svd(x0_t, y, A, Ap):                                                      # image_sample.py:376-380
+        return x0_t - Ap(A(x0_t.reshape(x0_t.size(0), -1)) - y.reshape(y.size(0), -1)).reshape(*x0_t.size())
+
+    def loss(x, y):                                                                      # image_sample.py:325-333 (svd / inpainting_random)
+        y_hat = op.A(x)
+        x_hat = op.A_pinv(y).view(x.shape)
+        return (torch.linalg.vector_norm(y_hat - y, ord=1, dim=1).cpu(),
+                torch.linalg.vector_norm(x_hat - x, ord=1, dim=(1, 2, 3)).cpu())
+
+    eps, sig, _ = models["simple_tiny"]
+    steps, seed = 10, 1234
+    sch = get_sampler("ddim", 1000, steps, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    exp = ImageExperiment(eps, sch, batch_size=B, data_shape=(C, res, res), seed=seed, device="cpu", save_folder="/tmp")
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 54.63)
+    exp.set_clip_fn("clamp")
+    gen = exp.new_gen()
+    z = torch.randn((B, C, res, res), generator=gen)
+    gen = exp.new_gen()
+    x, logs = exp.denoise_loop(shape=(B, C, res, res), gen=gen, style="pred", constrain_fn=partial(affine_svd, y=y, A=op.A, Ap=op.A_pinv),
+                               norm_eps=True, refine_prior_sigma=True, return_log=True, chunk_size=1, constrain_loss=partial(loss, y=y),
+                               sigma_pred_threshold=960)
+    save("inpaint", missing=missing, x_gt=x_gt, y=y, apy=apy, z=z, x=x, const_loss=torch.stack(logs[4]),
+         cfg=json.dumps(dict(res=res, steps=steps, seed=seed, B=B)))
+
+
 def main():
     _stub_missing_modules()
     torch.manual_seed(0)
@@ -276,6 +318,7 @@ def main():
     gen_nets(models)
     gen_sched()
     gen_loops(models)
+    gen_inpaint(models)
 
 
 if __name__ == "__main__":

@@ -49,7 +49,7 @@ def test_param_spec_matches_reference_state_dict(tag):
 def test_library_exports_every_declared_symbol():
     from diffusion_nlc_amd import _ext
     header = (ROOT / "include" / "nlc_hip.h").read_text()
-    declared = set(re.findall(r"\b(nlc_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(nlc_[A-Za-z0-9_]+)\s*\(", header))
     declared -= {"nlc_conv_desc", "nlc_sched_desc"}
     lib = _ext.load()
     for name in sorted(declared):

@@ -106,3 +106,44 @@ def test_edm_evaluate_runs_and_is_deterministic():
     assert a.shape == (4, 3, 32, 32) and torch.equal(a, b) and a.min() >= 0 and a.max() <= 1
     with pytest.raises(ValueError):
         exp.evaluate_edm(3)
+
+
+def test_inpainting_operator_and_constrained_loop():
+    """SURVEY §8 f-1 / BASELINE config 4 (reduced): Inpainting.A / A_pinv and a constrained DDIM+NLC loop vs the reference."""
+    from functools import partial
+    from diffusion_nlc_amd.constraint_functions import Constraint_Function, Inpainting
+    from diffusion_nlc_amd.experiments import ImageExperiment
+    from diffusion_nlc_amd.schedulers import get_sampler
+    g = load_npz("inpaint")
+    c = g["cfg"]
+    res, B = c["res"], c["B"]
+    op = Inpainting(3, res, g["missing"], "cuda:0")
+    y = op.A(g["x_gt"])
+    assert torch.equal(y.cpu(), g["y"])                                            # pure gather: bit exact
+    assert torch.equal(op.A_pinv(y).view(B, 3, res, res).cpu(), g["apy"])
+    cf = Constraint_Function("inpainting_random", op, channels=3, image_size=res)
+    eps, sig = _models("simple_tiny", torch.float32)
+    s = get_sampler("ddim", 1000, c["steps"], sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    s.to("cuda:0")
+    exp = ImageExperiment(eps, s, batch_size=B, data_shape=(3, res, res), seed=c["seed"], device="cuda:0")
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 54.63)
+    exp.set_clip_fn("clamp")
+    shape = (B, 3, res, res)
+    # (1) reference-shaped call: generic callable + per-step constraint loss (logging on)
+    x1, logs = exp.denoise_loop(shape=shape, gen=exp.new_gen(), style="pred", constrain_fn=partial(cf.constraint_fn, y=y),
+                                norm_eps=True, refine_prior_sigma=True, return_log=True, chunk_size=1,
+                                constrain_loss=partial(cf.loss, y=y), sigma_pred_threshold=960)
+    e1 = max_err(x1, g["x"])
+    # after the projection the forward loss is pure rounding residue (~1e-5): compare absolutely
+    el = (torch.stack(logs[4]).double() - g["const_loss"].double()).abs().max().item()
+    # (2) fused path: the projection runs inside nlc_sched_step
+    x2, _ = exp.denoise_loop(shape=shape, gen=exp.new_gen(), style="pred", constrain_fn=cf.bind(y, shape), norm_eps=True,
+                             refine_prior_sigma=True, return_log=False, chunk_size=1, constrain_loss=partial(cf.loss, y=y),
+                             sigma_pred_threshold=960)
+    e2 = max_err(x2, g["x"])
+    print(f"inpaint: L-inf generic {e1:.2e}, fused {e2:.2e}, const-loss abs {el:.2e}")
+    assert e1 < 1e-3 and e2 < 1e-3 and el < 1e-3
+    known = g["apy"][:, :, :, :]
+    mask = op.mask_chw.view(3, res, res).cpu().bool()
+    assert torch.equal(x2[:, mask], known[:, mask])                                # known pixels are copied exactly
