@@ -68,6 +68,16 @@ class SchedDesc(C.Structure):
     ]
 
 
+class SigmaDesc(C.Structure):
+    _fields_ = [
+        ("sumsq", C.c_void_p), ("sigma_in", C.c_void_p), ("t_in", C.c_void_p), ("sigmas", C.c_void_p), ("t_slopes", C.c_void_p),
+        ("sigma_t", C.c_void_p), ("sigma_prev", C.c_void_p), ("t", C.c_void_p), ("c_in", C.c_void_p),
+        ("sqrt_dim", C.c_float), ("norm_max", C.c_float), ("norm_min", C.c_float),
+        ("sigma_sched", C.c_float), ("sigma_prev_sched", C.c_float), ("t_sched", C.c_float), ("time_shift", C.c_float),
+        ("refine", C.c_int32), ("prev_is_ratio", C.c_int32), ("n_sigmas", C.c_int32), ("B", C.c_int32),
+    ]
+
+
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/nlc_hip.h declares
@@ -88,7 +98,9 @@ SIGNATURES = {
     "nlc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "nlc_row_sumsq": (C.c_int, [_vp, _vp, _i, _i64, _i64, _vp]),
     "nlc_refine_sigma": (C.c_int, [_vp, _f, _f, _f, _f, _f, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
-    "nlc_sigma_correct": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "nlc_refine_sigma_ex": (C.c_int, [C.POINTER(SigmaDesc), _vp]),
+    "nlc_sigma_correct": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "nlc_proj_sigma": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "nlc_dynamic_threshold": (C.c_int, [_vp, _f, _f, _vp, _i, _i64, _vp]),
     "nlc_sched_x0": (C.c_int, [C.POINTER(SchedDesc), _vp]),
     "nlc_sched_step": (C.c_int, [C.POINTER(SchedDesc), _vp, _vp]),

@@ -56,55 +56,94 @@ __device__ __forceinline__ int lower_bound(const float* __restrict__ table, int 
     return lo;
 }
 
-__global__ __launch_bounds__(RT) void refine_sigma_kernel(const float* __restrict__ sumsq, float sqrt_dim, float norm_max,
-                                                          float norm_min, float sigma_sched, float sigma_prev_sched,
-                                                          int refine, const float* __restrict__ sigmas, int n_sigmas,
-                                                          int t_sched, int time_shift, float* __restrict__ sigma_t,
-                                                          float* __restrict__ sigma_prev, float* __restrict__ t,
-                                                          float* __restrict__ c_in, int B) {
-    __shared__ int s_min;
-    if (threadIdx.x == 0) s_min = 0x7fffffff;
-    __syncthreads();
-    // pass 1: sigma and integer t per sample, batch minimum of t (src/experiments.py:411)
+// sigma -> t.  Discrete schedules: left searchsorted (src/schedulers.py:185-190).  Continuous-t schedules
+// (slopes != null): Interp1d of (sigmas, arange) as sigma_to_t_interp does (src/schedulers.py:210-220,
+// src/torchinterp1d.py:10-154): ind = clamp(searchsorted-1, 0, n-2); t = ind + slope[ind]*(v - sigmas[ind]),
+// slope[i] = 1/(eps + sigmas[i+1]-sigmas[i]) precomputed on the host in f32 exactly as the reference does.
+__device__ __forceinline__ float t_lookup(const float* __restrict__ sigmas, const float* __restrict__ slopes, int n, float v) {
+    const int lb = lower_bound(sigmas, n, v);
+    if (slopes == nullptr) return (float)lb;
+    const int ind = min(max(lb - 1, 0), n - 2);
+    return (float)ind + slopes[ind] * (v - sigmas[ind]);
+}
+
+__global__ __launch_bounds__(RT) void refine_sigma_kernel(nlc_sigma_desc d) {
+    __shared__ float sh[RT / 64];
+    __shared__ float s_min;
+    const int B = d.B;
+    // pass 1: sigma and t per sample, batch minimum of t (src/experiments.py:411)
+    float tmin = 3.0e38f;
     for (int b = threadIdx.x; b < B; b += RT) {
-        float sg = sigma_sched; int ti = t_sched;
-        if (refine) {
-            const float norm_x = sqrtf(sumsq[b]) / sqrt_dim;
-            const float min_dist = fmaxf(norm_x - norm_max, 0.f);
-            const float max_dist = norm_x + norm_min;
-            sg = fminf(fmaxf(sigma_sched, min_dist), max_dist);
-            ti = lower_bound(sigmas, n_sigmas, sg);
-            atomicMin(&s_min, ti);
+        const float raw = d.sigma_in ? d.sigma_in[b] : d.sigma_sched;
+        float sg = raw;
+        float tf = d.t_in ? d.t_in[b] : d.t_sched;
+        if (d.refine) {
+            const float norm_x = sqrtf(d.sumsq[b]) / d.sqrt_dim;
+            const float min_dist = fmaxf(norm_x - d.norm_max, 0.f);
+            const float max_dist = norm_x + d.norm_min;
+            sg = fminf(fmaxf(raw, min_dist), max_dist);
+            tf = t_lookup(d.sigmas, d.t_slopes, d.n_sigmas, sg);
+            tmin = fminf(tmin, tf);
         }
-        sigma_t[b] = sg;
-        sigma_prev[b] = sigma_prev_sched;
-        t[b] = (float)ti;   // provisional
+        d.sigma_t[b] = sg;
+        d.sigma_prev[b] = d.prev_is_ratio ? raw * d.sigma_prev_sched : d.sigma_prev_sched;
+        d.t[b] = tf;   // provisional
+    }
+    // block minimum (wave shuffle + one LDS round)
+    for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = tmin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = sh[0];
+        for (int i = 1; i < RT / 64; ++i) m = fminf(m, sh[i]);
+        s_min = m;
     }
     __syncthreads();
-    const int shift = (refine && s_min > 0) ? time_shift : 0;
+    const float shift = (d.refine && s_min > 0.f) ? d.time_shift : 0.f;
     for (int b = threadIdx.x; b < B; b += RT) {
-        float tf = t[b] - (float)shift;
+        float tf = d.t[b] - shift;
         tf = fminf(fmaxf(tf, 0.f), 1000.f);
-        t[b] = tf;
-        const float sg = sigma_t[b];
-        c_in[b] = sqrtf(1.0f / (sg * sg + 1.0f));
+        d.t[b] = tf;
+        const float sg = d.sigma_t[b];
+        d.c_in[b] = sqrtf(1.0f / (sg * sg + 1.0f));
     }
 }
 
-__global__ void sigma_correct_kernel(const float* __restrict__ r, int partial, const float* __restrict__ sigmas, int n_sigmas,
-                                     float* __restrict__ sigma_t, float* __restrict__ sigma_prev, float* __restrict__ t,
-                                     float* __restrict__ c_in, int B) {
+__global__ void sigma_correct_kernel(const float* __restrict__ r, int partial, const float* __restrict__ sigmas,
+                                     const float* __restrict__ slopes, int n_sigmas, float* __restrict__ sigma_t,
+                                     float* __restrict__ sigma_prev, float* __restrict__ t, float* __restrict__ c_in, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float st = sigma_t[b], sp = sigma_prev[b];
     const float dist_hat = st * (1.0f + r[b]);
     const float dist_prev_hat = dist_hat * (sp / st);
-    float tf = (float)lower_bound(sigmas, n_sigmas, dist_hat);
+    float tf = t_lookup(sigmas, slopes, n_sigmas, dist_hat);
     tf = fminf(fmaxf(tf, 0.f), 1000.f);
     sigma_t[b] = dist_hat;
     if (!partial) sigma_prev[b] = dist_prev_hat;
     t[b] = tf;
     c_in[b] = sqrtf(1.0f / (dist_hat * dist_hat + 1.0f));
+}
+
+// projection_loop's sigma re-estimation (image_sample.py:485-497), one thread per sample:
+//   cur_norm = ||x_prev|| / sqrt(D) ; cur_dist = sqrt(cur_norm^2 + norm_max^2 - 2 cur_norm norm_max cos + 1e-8)
+//   sigma <- term0 + r1*sigma_prev + r2*(sigma_t * cur_norm/last_norm) + r3*cur_dist ; t <- lookup(sigma)
+__global__ void proj_sigma_kernel(const float* __restrict__ sumsq, float sqrt_dim, float norm_max, float norm_max_sq,
+                                  float costheta, float term0, float r1, float r2, float r3,
+                                  const float* __restrict__ sigmas, const float* __restrict__ slopes, int n_sigmas,
+                                  float* __restrict__ last_norm, float* __restrict__ sigma_t,
+                                  const float* __restrict__ sigma_prev, float* __restrict__ t, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float cur_norm = sqrtf(sumsq[b]) / sqrt_dim;
+    const float cur_dist = sqrtf(((cur_norm * cur_norm + norm_max_sq) - ((2.0f * cur_norm) * norm_max) * costheta) + 1e-8f);
+    const float norm_ratio = cur_norm / last_norm[b];
+    const float s1 = sigma_prev[b];
+    const float s2 = sigma_t[b] * norm_ratio;
+    const float sg = ((term0 + r1 * s1) + r2 * s2) + r3 * cur_dist;
+    sigma_t[b] = sg;
+    t[b] = t_lookup(sigmas, slopes, n_sigmas, sg);
+    last_norm[b] = cur_norm;
 }
 
 // ---- exact per-sample quantile of |x| (torch.quantile, linear interpolation) by radix select.
@@ -330,25 +369,45 @@ extern "C" int nlc_row_sumsq(const float* x, float* sumsq, int B, int64_t row_st
     return NLC_OK;
 }
 
+extern "C" int nlc_refine_sigma_ex(const nlc_sigma_desc* d, void* stream) {
+    NLC_REQUIRE(d, "nlc_refine_sigma_ex: null descriptor");
+    NLC_REQUIRE(d->sigma_t && d->sigma_prev && d->t && d->c_in && d->B > 0, "nlc_refine_sigma_ex: null output / bad B");
+    NLC_REQUIRE(!d->refine || (d->sumsq && d->sigmas && d->n_sigmas > 1), "nlc_refine_sigma_ex: refine needs sumsq and the sigma table");
+    NLC_REQUIRE(!d->prev_is_ratio || d->sigma_prev_sched >= 0.f, "nlc_refine_sigma_ex: negative sigma_prev ratio");
+    hipLaunchKernelGGL(refine_sigma_kernel, dim3(1), dim3(RT), 0, (hipStream_t)stream, *d);
+    NLC_CHECK_LAUNCH("nlc_refine_sigma_ex");
+    return NLC_OK;
+}
+
 extern "C" int nlc_refine_sigma(const float* sumsq, float sqrt_dim, float norm_max, float norm_min, float sigma_sched,
                                 float sigma_prev_sched, int refine, const float* sigmas, int n_sigmas, int t_sched,
                                 int time_shift, float* sigma_t, float* sigma_prev, float* t, float* c_in, int B,
                                 void* stream) {
-    NLC_REQUIRE(sigma_t && sigma_prev && t && c_in && B > 0, "nlc_refine_sigma: null output / bad B");
-    NLC_REQUIRE(!refine || (sumsq && sigmas && n_sigmas > 0), "nlc_refine_sigma: refine needs sumsq and the sigma table");
-    hipLaunchKernelGGL(refine_sigma_kernel, dim3(1), dim3(RT), 0, (hipStream_t)stream, sumsq, sqrt_dim, norm_max, norm_min,
-                       sigma_sched, sigma_prev_sched, refine, sigmas, n_sigmas, t_sched, time_shift, sigma_t, sigma_prev, t,
-                       c_in, B);
-    NLC_CHECK_LAUNCH("nlc_refine_sigma");
+    nlc_sigma_desc d{};
+    d.sumsq = sumsq; d.sqrt_dim = sqrt_dim; d.norm_max = norm_max; d.norm_min = norm_min; d.sigma_sched = sigma_sched;
+    d.sigma_prev_sched = sigma_prev_sched; d.refine = refine; d.sigmas = sigmas; d.n_sigmas = n_sigmas;
+    d.t_sched = (float)t_sched; d.time_shift = (float)time_shift; d.sigma_t = sigma_t; d.sigma_prev = sigma_prev; d.t = t;
+    d.c_in = c_in; d.B = B;
+    return nlc_refine_sigma_ex(&d, stream);
+}
+
+extern "C" int nlc_sigma_correct(const float* r, int partial, const float* sigmas, const float* t_slopes, int n_sigmas,
+                                 float* sigma_t, float* sigma_prev, float* t, float* c_in, int B, void* stream) {
+    NLC_REQUIRE(r && sigmas && sigma_t && sigma_prev && t && c_in && B > 0 && n_sigmas > 1, "nlc_sigma_correct: bad arguments");
+    hipLaunchKernelGGL(sigma_correct_kernel, dim3(cdiv(B, NT)), dim3(NT), 0, (hipStream_t)stream, r, partial, sigmas, t_slopes,
+                       n_sigmas, sigma_t, sigma_prev, t, c_in, B);
+    NLC_CHECK_LAUNCH("nlc_sigma_correct");
     return NLC_OK;
 }
 
-extern "C" int nlc_sigma_correct(const float* r, int partial, const float* sigmas, int n_sigmas, float* sigma_t,
-                                 float* sigma_prev, float* t, float* c_in, int B, void* stream) {
-    NLC_REQUIRE(r && sigmas && sigma_t && sigma_prev && t && c_in && B > 0 && n_sigmas > 0, "nlc_sigma_correct: bad arguments");
-    hipLaunchKernelGGL(sigma_correct_kernel, dim3(cdiv(B, NT)), dim3(NT), 0, (hipStream_t)stream, r, partial, sigmas, n_sigmas,
-                       sigma_t, sigma_prev, t, c_in, B);
-    NLC_CHECK_LAUNCH("nlc_sigma_correct");
+extern "C" int nlc_proj_sigma(const float* sumsq, float sqrt_dim, float norm_max, float norm_max_sq, float costheta,
+                              float term0, float r1, float r2, float r3, const float* sigmas, const float* t_slopes,
+                              int n_sigmas, float* last_norm, float* sigma_t, const float* sigma_prev, float* t, int B,
+                              void* stream) {
+    NLC_REQUIRE(sumsq && sigmas && last_norm && sigma_t && sigma_prev && t && B > 0 && n_sigmas > 1, "nlc_proj_sigma: bad arguments");
+    hipLaunchKernelGGL(proj_sigma_kernel, dim3(cdiv(B, NT)), dim3(NT), 0, (hipStream_t)stream, sumsq, sqrt_dim, norm_max,
+                       norm_max_sq, costheta, term0, r1, r2, r3, sigmas, t_slopes, n_sigmas, last_norm, sigma_t, sigma_prev, t, B);
+    NLC_CHECK_LAUNCH("nlc_proj_sigma");
     return NLC_OK;
 }
 

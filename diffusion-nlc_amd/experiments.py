@@ -174,22 +174,28 @@ class ExperimentDiffusion:
             self._dev_state = st
         return st
 
-    def _nlc_step(self, xt, t_sched, sigma_sched, sigma_prev_sched, style, norm_eps, refine):
-        """get_denoise_vector (src/experiments.py:399-460) on the device.  Returns (eps_out, eps_sumsq)."""
+    def _nlc_step(self, xt, t_sched, sigma_sched, sigma_prev_sched, style, norm_eps, refine, per_sample=False,
+                  prev_is_ratio=False):
+        """get_denoise_vector (src/experiments.py:399-460) on the device.  Returns (eps_out, eps_sumsq).
+        ``per_sample``: the scheduled sigma_t / t are the per-sample vectors already in the device state
+        (projection_loop, image_sample.py:461-497); ``prev_is_ratio``: sigma_prev = sigma_t * sigma_prev_sched."""
         S = self.scheduler
         B = xt.shape[0]
         st = self._state(B)
+        slopes = S.device_t_slopes(self.device)
         sumsq = ops.row_sumsq(xt) if refine else None
         ops.refine_sigma(sumsq, math.sqrt(self.dim), self.norm_max, self.norm_min, float(sigma_sched),
                          float(sigma_prev_sched), refine, S.device_sigmas(self.device) if refine else None,
-                         int(t_sched), self.time_shift, st["sigma_t"], st["sigma_prev"], st["t"], st["c_in"])
+                         float(t_sched), self.time_shift, st["sigma_t"], st["sigma_prev"], st["t"], st["c_in"],
+                         sigma_in=st["sigma_t"] if per_sample else None, t_in=st["t"] if per_sample else None,
+                         prev_is_ratio=prev_is_ratio, t_slopes=slopes if refine else None)
         if "pred" in style:
             if self.sigma_model is None:
                 raise NlcError("style '%s' needs a sigma model (set_model)" % style)
             feat = self.model.run(xt, st["t"], mode="encode", in_scale=st["c_in"], feat_nhwc=True)
             r = self.sigma_model.run_nhwc(feat)
             ops.sigma_correct(r, style != "pred", S.device_sigmas(self.device), st["sigma_t"], st["sigma_prev"], st["t"],
-                              st["c_in"])
+                              st["c_in"], t_slopes=slopes)
         eps_out = self.model.run(xt, st["t"], mode="forward", in_scale=st["c_in"])
         C = self.data_shape[0]
         if self.learn_epsvar and eps_out.shape[1] != 2 * C:
@@ -197,13 +203,62 @@ class ExperimentDiffusion:
         es = ops.row_sumsq(eps_out, d_used=self.dim) if norm_eps else None
         return eps_out, es
 
+    def _sched_update(self, xt, eps_out, es, ind, constrain_fn, use_constraint, return_log, noise_list):
+        """pred_xstart -> clip -> (constraint) -> pred_xprev (src/experiments.py:360-370) as fused kernels.
+        Returns (x0_hat, x0, x_prev, eps_used)."""
+        S = self.scheduler
+        dev = self.device
+        B, C = xt.shape[0], xt.shape[1]
+        HW = xt.numel() // (B * C)
+        st = self._state(B)
+        stochastic = S.eta > 0 or S.variant in ("ddpm", "ddpm_orig")
+        noise = None
+        if stochastic:
+            noise = (noise_list[ind] if noise_list is not None else torch.randn(xt.shape)).to(dev, torch.float32).contiguous()
+        x0 = torch.empty_like(xt)
+        x_prev = torch.empty_like(xt)
+        eps_used = torch.empty_like(xt) if return_log else None
+        var_mode = VAR_MODES[S.sampler_var]
+        if var_mode == VAR_MODES["learned"] and not self.learn_epsvar:
+            raise NlcError("sampler_var 'learned' needs a network with learned variance (learn_epsvar)")
+        d = SchedDesc(xt=xt.data_ptr(), eps_out=eps_out.data_ptr(), noise=None if noise is None else noise.data_ptr(),
+                      sigma_t=st["sigma_t"].data_ptr(), sigma_prev=st["sigma_prev"].data_ptr(),
+                      eps_norm_sumsq=None if es is None else es.data_ptr(), x0=x0.data_ptr(), x_prev=x_prev.data_ptr(),
+                      eps_used=None if eps_used is None else eps_used.data_ptr(), B=B, C=C, Cnet=eps_out.shape[1], HW=HW,
+                      variant=SCHED_VARIANTS[S.variant], clip=CLIP_MODES[self.clip_kind], var_mode=var_mode, phases=0,
+                      eta=float(S.eta), min_var_coef=float(S.min_var_coef))
+        ops.sched_x0(d)
+        if self.clip_kind == "dynamic":
+            dyn = ops.dynamic_threshold(x0, 0.99, 100.0)
+            d.dyn_s = dyn.data_ptr()
+        fused_mask = use_constraint and not return_log and hasattr(constrain_fn, "mask_chw") and hasattr(constrain_fn, "known")
+        if fused_mask:
+            # inpainting projection x0 - A^+(A x0 - y) == "copy the known pixels": one fused kernel does
+            # clip + projection + x_prev (SURVEY.md §8 f-1)
+            d.mask, d.known = constrain_fn.mask_chw.data_ptr(), constrain_fn.known.data_ptr()
+            ops.sched_step(d, st["nan"])
+            x0_hat = x0
+        elif use_constraint or (return_log and constrain_fn is not None):
+            d.phases = 1                                   # clip only
+            ops.sched_step(d)
+            x0_hat = x0.clone() if return_log else x0
+            if use_constraint:
+                x0 = constrain_fn(x0).to(dev, torch.float32).contiguous()
+                d.x0 = x0.data_ptr()
+            d.phases = 2
+            ops.sched_step(d, st["nan"])
+        else:
+            ops.sched_step(d, st["nan"])
+            x0_hat = x0
+        return x0_hat, x0, x_prev, eps_used
+
     @torch.no_grad()
     def get_denoise_vector(self, xt, t, sigma_t, sigma_prev, style="base", norm_eps=False, refine_prior_sigma=False,
                            chunk_size=2):
         """Reference-shaped wrapper: returns (eps_mean, eps_logvar, sigma_t, sigma_prev) as (B,..) GPU tensors."""
         xt = xt.to(self.device, torch.float32).contiguous()
         B, C = xt.shape[0], self.data_shape[0]
-        eps_out, es = self._nlc_step(xt, int(t), float(sigma_t), float(sigma_prev), style, norm_eps, refine_prior_sigma)
+        eps_out, es = self._nlc_step(xt, float(t), float(sigma_t), float(sigma_prev), style, norm_eps, refine_prior_sigma)
         st = self._state(B)
         eps = eps_out[:, :C].contiguous()
         if es is not None:
@@ -220,25 +275,21 @@ class ExperimentDiffusion:
         stochastic samplers consume; by default they come from the global CPU generator, one
         ``randn(shape)`` per step, in step order."""
         S = self.scheduler
-        if getattr(S, "continuous_t", False):
-            raise NotImplementedError("continuous-t schedules (sigma_style Linear/Scaled, redesign) are not on the HIP path yet")
         S.reset_state()
         dev = self.device
-        sig_host = S.sampling_sigmas.detach().cpu().float()
+        sig_host = S.sampling_sigmas.detach().cpu()
         ts_host = S.timesteps.detach().cpu()
         if xT is None:
             xt, zt = self.get_noise_xt(shape=shape, gen=gen, norm_noise=norm_init_noise, sigma=sig_host[0])
         else:
             xt = xT.to(dev, torch.float32).contiguous()
             zt = self.convert_coordinate(xt, sigma=sig_host[0]) if return_log else None
-        B, C = xt.shape[0], xt.shape[1]
-        HW = xt.numel() // (B * C)
+        B = xt.shape[0]
         st = self._state(B)
         z_list, eps_list, x0_prec_list, x0_postc_list, const_loss_list = [], [], [], [], []
         if return_log:
             z_list = [zt.cpu()]
         eta0 = S.eta
-        variant = SCHED_VARIANTS[S.variant]
         best_val, best_x0 = 10000, xt
         x0 = xt
         st["nan"].zero_()
@@ -249,50 +300,11 @@ class ExperimentDiffusion:
             if t > sigma_pred_threshold:
                 cur_style, cur_refine = "base", False
             eps_out, es = self._nlc_step(xt, t, sig_host[ind], sig_host[ind + 1], cur_style, bool(norm_eps), cur_refine)
-            stochastic = S.eta > 0 or S.variant in ("ddpm", "ddpm_orig")
-            noise = None
-            if stochastic:
-                noise = (noise_list[ind] if noise_list is not None else torch.randn(xt.shape)).to(dev, torch.float32).contiguous()
-            x0 = torch.empty_like(xt)
-            x_prev = torch.empty_like(xt)
-            eps_used = torch.empty_like(xt) if return_log else None
-            var_mode = VAR_MODES[S.sampler_var]
-            if var_mode == VAR_MODES["learned"] and not self.learn_epsvar:
-                raise NlcError("sampler_var 'learned' needs a network with learned variance (learn_epsvar)")
-            d = SchedDesc(xt=xt.data_ptr(), eps_out=eps_out.data_ptr(), noise=None if noise is None else noise.data_ptr(),
-                          sigma_t=st["sigma_t"].data_ptr(), sigma_prev=st["sigma_prev"].data_ptr(),
-                          eps_norm_sumsq=None if es is None else es.data_ptr(), x0=x0.data_ptr(), x_prev=x_prev.data_ptr(),
-                          eps_used=None if eps_used is None else eps_used.data_ptr(), B=B, C=C, Cnet=eps_out.shape[1], HW=HW,
-                          variant=variant, clip=CLIP_MODES[self.clip_kind], var_mode=var_mode, phases=0,
-                          eta=float(S.eta), min_var_coef=float(S.min_var_coef))
-            ops.sched_x0(d)
-            dyn = None
-            if self.clip_kind == "dynamic":
-                dyn = ops.dynamic_threshold(x0, 0.99, 100.0)
-                d.dyn_s = dyn.data_ptr()
-            x0_hat = None
             use_constraint = constrain_fn is not None and (free_const_steps <= 0 or ind <= free_const_steps)
-            fused_mask = use_constraint and not return_log and hasattr(constrain_fn, "mask_chw") and hasattr(constrain_fn, "known")
-            if fused_mask:
-                # inpainting projection x0 - A^+(A x0 - y) == "copy the known pixels": one fused kernel does
-                # clip + projection + x_prev
-                d.mask, d.known = constrain_fn.mask_chw.data_ptr(), constrain_fn.known.data_ptr()
-                ops.sched_step(d, st["nan"])
-                x0_hat = x0
-            elif use_constraint or (return_log and constrain_fn is not None):
-                d.phases = 1                                   # clip only
-                ops.sched_step(d)
-                x0_hat = x0.clone() if return_log else x0
-                if use_constraint:
-                    x0 = constrain_fn(x0).to(dev, torch.float32).contiguous()
-                    d.x0 = x0.data_ptr()
-                d.phases = 2
-                ops.sched_step(d, st["nan"])
-            else:
-                ops.sched_step(d, st["nan"])
-                x0_hat = x0
+            x0_hat, x0, x_prev, eps_used = self._sched_update(xt, eps_out, es, ind, constrain_fn, use_constraint, return_log,
+                                                             noise_list)
             S.i += 1
-            xt_prev, xt = xt, x_prev
+            xt = x_prev
             if constrain_loss is not None:
                 const, _ = constrain_loss(x0.clamp(-1, 1))
                 const_val = torch.mean(const)
@@ -312,6 +324,93 @@ class ExperimentDiffusion:
         S.eta = eta0
         out = (best_x0 if return_best else x0).cpu()
         return out, [z_list, eps_list, x0_prec_list, x0_postc_list, const_loss_list]
+
+    @torch.no_grad()
+    def projection_loop(self, shape, gen=None, norm_init_noise=False, style="base", constrain_fn=None, norm_eps=False,
+                        refine_prior_sigma=False, xT=None, return_log=False, chunk_size=2, sigma_estimate_rate=(1, 0, 0, 0),
+                        constrain_loss=None, stop_condition=0.0, max_T=None, sigma_pred_threshold=1000, new_eta=None,
+                        recal_sigma_prev=False, noise_list=None):
+        """The 'project' sampling mode (image_sample.py:431-519): denoise_loop whose next (sigma_t, t) are
+        re-estimated per sample from the norm of the new state (4-way blend ``sigma_estimate_rate``), with
+        optional ``recal_sigma_prev`` and early stop on the constraint loss.  The per-sample sigma / t / last-norm
+        state never leaves the device; the only per-step host read is ``t.max() > sigma_pred_threshold``, which
+        the reference also does and which couples the batch (:471).
+        Returns (x_cpu, [z_list, eps_list, x0_prec_list, x0_postc_list, sigma_list, const_loss_list])."""
+        S = self.scheduler
+        rate = [float(r) for r in sigma_estimate_rate]
+        if len(rate) != 4:
+            raise ValueError("sigma_estimate_rate needs 4 entries (image_sample.py:495 indexes [0..3])")
+        if max_T is None:
+            max_T = len(S.timesteps) - 1
+        S.reset_state()
+        dev = self.device
+        sigs = S.sampling_sigmas.detach().cpu()
+        ts_host = S.timesteps.detach().cpu()
+        if xT is None:
+            xt, zt = self.get_noise_xt(shape=shape, gen=gen, norm_noise=norm_init_noise, sigma=sigs[0])
+        else:
+            xt = xT.to(dev, torch.float32).contiguous()
+            zt = self.convert_coordinate(xt, sigma=sigs[0]) if return_log else None
+        B = xt.shape[0]
+        st = self._state(B)
+        x0 = xt
+        eps_list, z_list, sigma_list, x0_prec_list, x0_postc_list, const_loss_list = [], [], [], [], [], []
+        costheta = 0.99
+        last_norm = ops.row_sumsq(xt).sqrt_().div_(math.sqrt(self.dim))
+        if return_log:
+            z_list = [zt.cpu()]
+            sigma_list = [sigs[0].clone()]
+        T = len(sigs)
+        best_val, best_x0 = 10000, x0
+        const_val = None
+        sample_time_step = len(ts_host)
+        eta0 = S.eta
+        st["nan"].zero_()
+        slopes = S.device_t_slopes(dev)
+        nm = float(self.norm_max)
+        for ind in range(max_T):
+            if ind == sample_time_step - 1 and new_eta is not None:
+                S.eta = new_eta
+            sigma_prev_orig = sigs[-1] if ind >= T - 1 else sigs[ind + 1]
+            per_sample = ind > 0
+            if recal_sigma_prev:
+                prev_arg, ratio = (sigs[ind + 1] / sigs[ind]), True          # sigma_prev = sigma_t * ratio (:463-464)
+                if not per_sample:
+                    prev_arg, ratio = sigs[0] * prev_arg, False
+            else:
+                prev_arg, ratio = sigma_prev_orig, False
+            cur_style, cur_refine = style, bool(refine_prior_sigma)
+            t_max = float(st["t"].max().item()) if per_sample else float(ts_host[0])
+            if t_max > sigma_pred_threshold:
+                cur_style, cur_refine = "base", False
+            eps_out, es = self._nlc_step(xt, ts_host[0], sigs[0], prev_arg, cur_style, bool(norm_eps), cur_refine,
+                                         per_sample=per_sample, prev_is_ratio=ratio)
+            x0_hat, x0, x_prev, eps_used = self._sched_update(xt, eps_out, es, ind, constrain_fn, constrain_fn is not None,
+                                                             return_log, noise_list)
+            xt = x_prev
+            if return_log:                                   # z uses the sigma_prev of THIS step: read before the update
+                z_list.append(ops.scale_rows(xt, torch.sqrt(1 / (st["sigma_prev"] ** 2 + 1))).cpu())
+            ops.proj_sigma(ops.row_sumsq(xt), math.sqrt(self.dim), nm, float(nm ** 2), costheta,
+                           float(rate[0] * sigma_prev_orig), rate[1], rate[2], rate[3], S.device_sigmas(dev), slopes,
+                           last_norm, st["sigma_t"], st["sigma_prev"], st["t"])
+            if constrain_loss is not None:
+                const, _ = constrain_loss(x0.clamp(-1, 1))
+                const_val = torch.mean(const)
+                if const_val < best_val:
+                    best_x0, best_val = x0, const_val
+                if return_log:
+                    const_loss_list.append(const.cpu())
+            else:
+                best_x0 = x0
+            if return_log:
+                eps_list.append(eps_used.cpu())
+                x0_prec_list.append(x0_hat.cpu())
+                x0_postc_list.append(x0.cpu())
+                sigma_list.append(st["sigma_t"].view(B, 1, 1, 1).cpu())
+            if (self.check_nan and int(st["nan"].item()) != 0) or (const_val is not None and const_val <= stop_condition):
+                break
+        S.eta = eta0
+        return best_x0.cpu(), [z_list, eps_list, x0_prec_list, x0_postc_list, sigma_list, const_loss_list]
 
     check_nan = True
 

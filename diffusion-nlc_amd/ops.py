@@ -314,22 +314,42 @@ def row_sumsq(x: torch.Tensor, d_used: Optional[int] = None) -> torch.Tensor:
 
 
 def refine_sigma(sumsq, sqrt_dim, norm_max, norm_min, sigma_sched, sigma_prev_sched, refine, sigmas, t_sched,
-                 time_shift, sigma_t, sigma_prev, t, c_in):
+                 time_shift, sigma_t, sigma_prev, t, c_in, sigma_in=None, t_in=None, prev_is_ratio=False, t_slopes=None):
+    """nlc_refine_sigma_ex.  ``sigma_in``/``t_in``: per-sample scheduled values (may alias the outputs);
+    ``t_slopes``: continuous-t interpolation slopes (None = discrete searchsorted)."""
     lib = _ext.load()
     B = sigma_t.shape[0]
-    check(lib.nlc_refine_sigma(_ptr(sumsq), sqrt_dim, norm_max, norm_min, sigma_sched, sigma_prev_sched,
-                               1 if refine else 0, _ptr(sigmas), 0 if sigmas is None else sigmas.shape[0],
-                               int(t_sched), int(time_shift), sigma_t.data_ptr(), sigma_prev.data_ptr(),
-                               t.data_ptr(), c_in.data_ptr(), B, _stream()), "nlc_refine_sigma")
+    for v, n in ((sigma_in, "sigma_in"), (t_in, "t_in")):
+        if v is not None and (v.dtype != torch.float32 or v.numel() != B or not v.is_contiguous()):
+            raise _ext.NlcError(f"refine_sigma: {n} must be a contiguous float32 [B] tensor")
+    if t_slopes is not None and (sigmas is None or t_slopes.numel() != sigmas.numel() - 1):
+        raise _ext.NlcError("refine_sigma: t_slopes needs the sigma table and n_sigmas-1 entries")
+    d = _ext.SigmaDesc(sumsq=_ptr(sumsq), sigma_in=_ptr(sigma_in), t_in=_ptr(t_in), sigmas=_ptr(sigmas), t_slopes=_ptr(t_slopes),
+                       sigma_t=sigma_t.data_ptr(), sigma_prev=sigma_prev.data_ptr(), t=t.data_ptr(), c_in=c_in.data_ptr(),
+                       sqrt_dim=sqrt_dim, norm_max=norm_max, norm_min=norm_min, sigma_sched=float(sigma_sched),
+                       sigma_prev_sched=float(sigma_prev_sched), t_sched=float(t_sched), time_shift=float(time_shift),
+                       refine=1 if refine else 0, prev_is_ratio=1 if prev_is_ratio else 0,
+                       n_sigmas=0 if sigmas is None else sigmas.shape[0], B=B)
+    check(lib.nlc_refine_sigma_ex(C.byref(d), _stream()), "nlc_refine_sigma_ex")
 
 
-def sigma_correct(r, partial, sigmas, sigma_t, sigma_prev, t, c_in):
+def sigma_correct(r, partial, sigmas, sigma_t, sigma_prev, t, c_in, t_slopes=None):
     lib = _ext.load()
     _need(r, torch.float32, "sigma_correct r")
     B = sigma_t.shape[0]
-    check(lib.nlc_sigma_correct(r.data_ptr(), 1 if partial else 0, sigmas.data_ptr(), sigmas.shape[0],
+    check(lib.nlc_sigma_correct(r.data_ptr(), 1 if partial else 0, sigmas.data_ptr(), _ptr(t_slopes), sigmas.shape[0],
                                 sigma_t.data_ptr(), sigma_prev.data_ptr(), t.data_ptr(), c_in.data_ptr(), B,
                                 _stream()), "nlc_sigma_correct")
+
+
+def proj_sigma(sumsq, sqrt_dim, norm_max, norm_max_sq, costheta, term0, r1, r2, r3, sigmas, t_slopes, last_norm, sigma_t,
+               sigma_prev, t):
+    """projection_loop's sigma re-estimation, in place on (last_norm, sigma_t, t) (image_sample.py:485-497)."""
+    lib = _ext.load()
+    B = sigma_t.shape[0]
+    check(lib.nlc_proj_sigma(sumsq.data_ptr(), sqrt_dim, norm_max, norm_max_sq, costheta, term0, r1, r2, r3, sigmas.data_ptr(),
+                             _ptr(t_slopes), sigmas.shape[0], last_norm.data_ptr(), sigma_t.data_ptr(), sigma_prev.data_ptr(),
+                             t.data_ptr(), B, _stream()), "nlc_proj_sigma")
 
 
 def dynamic_threshold(x0_hat: torch.Tensor, q: float, max_value: float) -> torch.Tensor:

@@ -115,6 +115,7 @@ class Scheduler:
         feeds the searchsorted kernels."""
         self.device = torch.device(device)
         self._dev_sigmas = None
+        self._dev_slopes = None
         return self
 
     def device_sigmas(self, device=None):
@@ -122,6 +123,19 @@ class Scheduler:
         if self._dev_sigmas is None or self._dev_sigmas.device != device:
             self._dev_sigmas = self.sigmas.to(device=device, dtype=torch.float32).contiguous()
         return self._dev_sigmas
+
+    def device_t_slopes(self, device=None):
+        """None for discrete schedules; for continuous-t schedules the Interp1d slopes of
+        sigma_to_t_interp (src/schedulers.py:210-220; src/torchinterp1d.py: slopes = dy / (eps + dx)), f32."""
+        if not self.continuous_t:
+            return None
+        device = torch.device(device) if device is not None else self.device
+        sl = getattr(self, "_dev_slopes", None)
+        if sl is None or sl.device != device:
+            x, y = self.sigmas.float(), self.train_timesteps.float()
+            sl = ((y[1:] - y[:-1]) / (torch.finfo(torch.float32).eps + (x[1:] - x[:-1]))).to(device).contiguous()
+            self._dev_slopes = sl
+        return sl
 
     def reset_state(self):
         self.state = {}
@@ -137,14 +151,16 @@ class Scheduler:
         xnew = t.squeeze()
         if xnew.dim() == 0:
             xnew = xnew.unsqueeze(0)
-        y = _interp1d(self.train_timesteps.float(), self.alphas_cumprod, xnew.float()).squeeze(0)
+        if not xnew.is_floating_point():
+            xnew = xnew.float()
+        y = _interp1d(self.train_timesteps.float(), self.alphas_cumprod, xnew).squeeze(0)
         return torch.where(t >= 0, (1 / y - 1).sqrt(), self.final_sigma).float()
 
     def sigma_to_t_interp(self, sigma):
         xnew = torch.as_tensor(sigma).cpu().squeeze()
         if xnew.dim() == 0:
             xnew = xnew.unsqueeze(0)
-        return _interp1d(self.sigmas, self.train_timesteps.float(), xnew.to(self.sigmas.dtype)).squeeze(0).float()
+        return _interp1d(self.sigmas, self.train_timesteps.float(), xnew).squeeze(0).float()   # xnew keeps its dtype (f64 tables promote)
 
     def sigma(self, timestep):
         timestep = torch.as_tensor(timestep).cpu()
@@ -343,4 +359,26 @@ def get_sampler(sampler_name, train_timesteps, inference_timesteps, beta_start=0
         end_sigma = sampler.sigmas[0] if (end_t is None or end_t < 0) else sampler.sigmas[end_t]
     sampler.set_timesteps_sigma(start=start_sigma, end=end_sigma, num_inference_steps=inference_timesteps,
                                 style=sigma_style, scale=linear_scale, continuous_t=continuous_t)
+    return sampler
+
+
+def redesign_sigma(sampler, num_timesteps, max_T, cycle_size, min_sigma, max_sigma, sigma_gamma):
+    """The '--redesign_sigma' tail of the sampling schedule (image_sample.py:788-800): after the ``num_timesteps``
+    scheduled steps, ``max_T - num_timesteps`` extra low-noise steps whose log-sigma follows a decaying
+    triangle wave between ``min_sigma`` and ``max_sigma`` (period ``cycle_size``, amplitude x ``sigma_gamma``
+    per cycle).  Switches the scheduler to continuous t; the resulting table is float64, as in the reference
+    (numpy exp -> torch.cat promotes)."""
+    if max_T <= num_timesteps:
+        return sampler
+    sampler.continuous_t = True
+    sampler._dev_slopes = None
+    it = np.arange(max_T - num_timesteps)
+    cycle = np.floor(1 + it / cycle_size)
+    x = np.abs(it / cycle_size - cycle + 1)
+    lo, hi = np.log(min_sigma), np.log(max_sigma)
+    tail = torch.tensor(np.exp(lo + (hi - lo) * np.maximum(0, 1 - x) * sigma_gamma ** (cycle - 1)))
+    sampler.sampling_sigmas = torch.cat([torch.clamp(sampler.sampling_sigmas[:-1], min=min_sigma), tail])
+    sampler.timesteps = sampler.get_t_from_sigma(sampler.sampling_sigmas)
+    sampler.timesteps = torch.cat([sampler.timesteps, torch.tensor([-1])])
+    sampler.sampling_sigmas = torch.cat([sampler.sampling_sigmas, torch.tensor([sampler.final_sigma])])
     return sampler

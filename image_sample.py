@@ -12,8 +12,10 @@ diffusion-nlc_amd/.  Differences, all on side effects the reference hard-codes:
   ``--return_log`` (default 0): the 2.5 GB-per-batch history is only copied to the host when asked for.
 * ``--synthetic NAME`` (extension): run without ``store/`` / ``results/`` files, with a built-in model
   configuration and the deterministic filler weights (the reference ships neither configs nor checkpoints).
-* ``--sampling project`` (projection_loop, σ-redesign, continuous t) is a SURVEY §8 "next" row and raises
-  NotImplementedError; so does any ``--constraint`` other than ``none``.
+* ``--constraint``: the inpainting operators (``inpainting``, ``inpainting_half``) with ``--constraint_proj svd``
+  run on the HIP path; the other SVD operators and the GD projections raise NotImplementedError.
+  With ``--synthetic`` the validation images are seeded U(0,1) tensors and the mask is the seeded random 50 %
+  of pixels of BASELINE config 4 (no dataset / ``store/inp_masks`` files ship with the reference).
 """
 from __future__ import annotations
 
@@ -34,7 +36,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from src.experiments import ImageExperiment                                    # noqa: E402
-from src.schedulers import get_sampler                                          # noqa: E402
+from src.schedulers import get_sampler, redesign_sigma                          # noqa: E402
 from src.script_util import create_sigma_eps_model, create_simple_sigma_eps_model   # noqa: E402
 from src.utils import get_model_size                                            # noqa: E402
 
@@ -48,7 +50,12 @@ SYNTHETIC = {
     "cifar_tiny": (dict(model=dict(type="simple", ch=64, out_ch=3, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[16],
                                    dropout=0.0, in_channels=3, resamp_with_conv=True, use_fp16=False),
                         diffusion=dict(num_diffusion_timesteps=1000, beta_schedule="linear"),
-                        data=dict(dataset="CIFAR10", image_size=32, channels=3, subset_1k=False)), "cifar10"),
+                        data=dict(dataset="CIFAR10", image_size=32, channels=3, subset_1k=False)), "celeba_hq"),
+    # BASELINE config 4: CelebA-HQ-256 DDPM UNet
+    "celebahq256": (dict(model=dict(type="simple", ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2,
+                                    attn_resolutions=[16], dropout=0.0, in_channels=3, resamp_with_conv=True, use_fp16=True),
+                         diffusion=dict(num_diffusion_timesteps=1000, beta_schedule="linear"),
+                         data=dict(dataset="CelebA_HQ", image_size=256, channels=3, subset_1k=False)), "celeba_hq"),
 }
 
 
@@ -207,11 +214,9 @@ def save_png(img, path):
 
 @torch.no_grad()
 def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=False, style="base", sampling="denoise",
-                          norm_eps=False, refine_prior_sigma=False, sigma_pred_threshold=1000, new_eta=None,
-                          return_log=False, save_images=True):
+                          norm_eps=False, refine_prior_sigma=False, sigma_estimate_rate=(1, 0, 0, 0), max_T=None,
+                          sigma_pred_threshold=1000, new_eta=None, recal_sigma_prev=False, return_log=False, save_images=True):
     """image_sample.py:522-569: ceil(n/B) full batches from ONE host generator, skip batches whose PNGs exist."""
-    if sampling == "project":
-        raise NotImplementedError("projection_loop is a SURVEY §8 'next' row (f-2); use --sampling denoise presets")
     B = experiment.batch_size
     shape = (B,) + experiment.data_shape
     gen = experiment.new_gen()
@@ -222,10 +227,18 @@ def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=Fal
             print("skip images for:", f"00-{i:05}-(000~{B - 1:03}).png")
             continue
         t1 = time()
-        sample, return_list = experiment.denoise_loop(shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
-                                                      constrain_fn=None, norm_eps=norm_eps, refine_prior_sigma=refine_prior_sigma,
-                                                      return_log=return_log, chunk_size=1, sigma_pred_threshold=sigma_pred_threshold,
-                                                      new_eta=new_eta)
+        if sampling == "project":
+            sample, return_list = projection_loop(experiment, shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
+                                                  constrain_fn=None, norm_eps=norm_eps, refine_prior_sigma=refine_prior_sigma,
+                                                  xT=None, return_log=return_log, chunk_size=1,
+                                                  sigma_estimate_rate=sigma_estimate_rate, constrain_loss=None, max_T=max_T,
+                                                  stop_condition=0.0, sigma_pred_threshold=sigma_pred_threshold, new_eta=new_eta,
+                                                  recal_sigma_prev=recal_sigma_prev)
+        else:
+            sample, return_list = experiment.denoise_loop(shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
+                                                          constrain_fn=None, norm_eps=norm_eps,
+                                                          refine_prior_sigma=refine_prior_sigma, return_log=return_log,
+                                                          chunk_size=1, sigma_pred_threshold=sigma_pred_threshold, new_eta=new_eta)
         print("time:", time() - t1)
         logs.append(return_list)
         sample = sample.add(1).div(2).clamp(0, 1)
@@ -237,9 +250,100 @@ def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=Fal
     return {"fid": fid}, logs
 
 
+def projection_loop(self, *args, **kwargs):
+    """image_sample.py:431-519 (free function taking the experiment as ``self``): the device implementation is
+    ExperimentDiffusion.projection_loop."""
+    return self.projection_loop(*args, **kwargs)
+
+
+def get_constraint_function(args, image_size, channels):
+    """image_sample.py:359-405 for the operators on the HIP path: inpainting with the 'svd' (or 'ddrm', same
+    operator) projection."""
+    from src.constraint_functions import Constraint_Function, svd_constraint
+    proj = "svd" if args.constraint_proj == "ddrm" else args.constraint_proj
+    if proj != "svd":
+        raise NotImplementedError(f"--constraint_proj {args.constraint_proj}: only 'svd' / 'ddrm' are on the HIP path")
+    name = args.constraint
+    if args.synthetic and name == "inpainting":
+        name = "inpainting_random"                 # seeded random 50 % mask instead of store/inp_masks/mask_random.pt
+    op = svd_constraint(name, fn_scale=args.constraint_scale, device=args.device, base_mask_dir="store/inp_masks",
+                        image_size=image_size, channels=channels)
+    return Constraint_Function(args.constraint, op, channels=channels, image_size=image_size, lr=args.constraint_lr)
+
+
+def synthetic_val_loader(args, shape, n_samples):
+    """Stand-in for get_val_loader (image_sample.py:407-428) when no dataset is available: seeded U(0,1) images."""
+    g = torch.Generator().manual_seed(args.seed)
+    for _ in range(max(1, math.ceil(n_samples / args.batch_size))):
+        yield torch.rand((args.batch_size,) + tuple(shape), generator=g), torch.zeros(args.batch_size, dtype=torch.long)
+
+
+@torch.no_grad()
+def evaluate_constraint(experiment, data_loader, Constraint, images_dir, n_samples=-1, norm_init_noise=False, style="base",
+                        sampling="denoise", norm_eps=False, refine_prior_sigma=False, prior_xt=False,
+                        sigma_estimate_rate=(1, 0, 0, 0), return_log=False, max_T=None, sigma_pred_threshold=1000, new_eta=None,
+                        recal_sigma_prev=False, save_images=True):
+    """image_sample.py:608-709 (SSIM needs basicsr and is skipped; PSNR / MSE / constraint losses are kept).
+    The projection runs fused inside the scheduler kernel (Constraint.bind) unless logging is on."""
+    device = experiment.device
+    gen = experiment.new_gen()
+    mse_list, psnr_list, const_f_loss, const_b_loss, const_orig_loss = [], [], [], [], []
+    return_list = None
+    for i, (x_orig, _classes) in enumerate(data_loader):
+        B = x_orig.shape[0]
+        paths = [os.path.join(images_dir, f"00-{i:05}-{j:03}.png") for j in range(B)]
+        if save_images and all(os.path.exists(p) for p in paths):
+            print("skip images for:", f"00-{i:05}-(000~{B - 1:03}).png")
+            continue
+        batch_x = 2 * x_orig.to(device) - 1.0
+        y = Constraint.transform(batch_x)
+        Apy = Constraint.inv_transform(y)
+        shape = (B,) + experiment.data_shape
+        from functools import partial
+        constraint_fn = partial(Constraint.constraint_fn, y=y, lambda_t=Constraint.lr) if return_log else Constraint.bind(y, shape)
+        constrain_loss = partial(Constraint.loss, y=y)
+        xT = None
+        if prior_xt:
+            xT = Apy + float(experiment.scheduler.sampling_sigmas[0]) * torch.randn(Apy.shape).to(device)
+        t1 = time()
+        if sampling == "project":
+            sample, return_list = projection_loop(experiment, shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
+                                                  constrain_fn=constraint_fn, norm_eps=norm_eps,
+                                                  refine_prior_sigma=refine_prior_sigma, xT=xT, return_log=return_log, chunk_size=1,
+                                                  sigma_estimate_rate=sigma_estimate_rate, constrain_loss=constrain_loss,
+                                                  max_T=max_T, stop_condition=0.0, sigma_pred_threshold=sigma_pred_threshold,
+                                                  new_eta=new_eta, recal_sigma_prev=recal_sigma_prev)
+        else:
+            sample, return_list = experiment.denoise_loop(shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
+                                                          constrain_fn=constraint_fn, norm_eps=norm_eps,
+                                                          refine_prior_sigma=refine_prior_sigma, xT=xT, return_log=return_log,
+                                                          chunk_size=1, constrain_loss=constrain_loss,
+                                                          sigma_pred_threshold=sigma_pred_threshold, new_eta=new_eta)
+        print("time:", time() - t1)
+        sample = sample.add(1).div(2).clamp(0, 1)
+        if save_images:
+            for img, p in zip(sample, paths):
+                save_png(img, p)
+        mse = torch.mean((sample - x_orig) ** 2, dim=(1, 2, 3))
+        psnr = 10 * torch.log10(1 / mse)
+        x_hat = (2 * sample - 1.0).to(device)
+        const_f, const_b = Constraint.loss(x_hat, y)
+        cons_orig = torch.linalg.vector_norm((x_hat - batch_x).cpu(), ord=1, dim=(1, 2, 3))
+        mse_list += mse.tolist(); psnr_list += psnr.tolist()
+        const_f_loss += const_f.tolist(); const_b_loss += const_b.tolist(); const_orig_loss += cons_orig.tolist()
+        print(f"done batches:{i},  psnr:{np.mean(psnr_list)}, cost:{np.mean(const_f_loss)}")
+        if n_samples > 0 and (i + 1) * B > n_samples:
+            break
+    fid = experiment.fid_fn(images_dir) if experiment.fid_fn is not None else float("nan")
+    log_dict = dict(mse=float(np.mean(mse_list)), psner=float(np.mean(psnr_list)), ssim=float("nan"),
+                    const_f_loss=float(np.mean(const_f_loss)), const_b_loss=float(np.mean(const_b_loss)),
+                    const_orig_loss=float(np.mean(const_orig_loss)), fid=fid,
+                    full_log=dict(psnr=psnr_list, mse=mse_list, const_forward=const_f_loss, const_backward=const_b_loss,
+                                  const_orig_loss=const_orig_loss))
+    return log_dict, return_list
+
+
 def main(args, config):
-    if args.constraint != "none":
-        raise NotImplementedError("restoration constraints are a SURVEY §8 'next' row (f-1)")
     if args.save_folder is not None:
         args.test_dir = args.save_folder
     else:
@@ -280,7 +384,8 @@ def main(args, config):
                           end_sigma=args.end_sigma, sampler_var=args.sampler_var, continuous_t=args.continuous_t,
                           linear_scale=args.linear_scale, eta=args.eta, norm_eps=args.norm_eps, start_t=args.start_t, end_t=args.end_t)
     if args.redesign_sigma and args.max_T > args.num_timesteps:
-        raise NotImplementedError("sigma redesign (image_sample.py:788-800) needs continuous t: SURVEY §8 'next' row f-2")
+        print("redesign sigma", args.num_timesteps, args.max_T)
+        redesign_sigma(sampler, args.num_timesteps, args.max_T, args.cycle_size, args.min_sigma, args.max_sigma, args.sigma_gamma)
     sampler.to(args.device)
 
     d = config.data
@@ -296,15 +401,30 @@ def main(args, config):
     if os.path.exists(images_dir) and args.sample_overwrite:
         shutil.rmtree(images_dir)
     os.makedirs(images_dir, exist_ok=True)
-    log_dict, return_lists = evaluate_unconstraint(
-        experiment, args.sample_size, images_dir, norm_init_noise=args.norm_init_noise, style=args.sigma_type,
-        sampling=args.sampling, norm_eps=args.norm_eps, refine_prior_sigma=args.refine_sigma,
-        sigma_pred_threshold=args.sigma_pred_threshold, new_eta=args.new_eta, return_log=bool(args.return_log),
-        save_images=bool(args.save_png))
-    if args.return_log:
-        torch.save(return_lists, os.path.join(args.test_dir, args.save_flag, "results_dump.pt"))
+    if args.constraint == "none":
+        log_dict, return_lists = evaluate_unconstraint(
+            experiment, args.sample_size, images_dir, norm_init_noise=args.norm_init_noise, style=args.sigma_type,
+            sampling=args.sampling, norm_eps=args.norm_eps, refine_prior_sigma=args.refine_sigma,
+            sigma_estimate_rate=args.sigma_estimate_rate, max_T=args.max_T, sigma_pred_threshold=args.sigma_pred_threshold,
+            new_eta=args.new_eta, recal_sigma_prev=args.recal_sigma_prev, return_log=bool(args.return_log),
+            save_images=bool(args.save_png))
+        if args.return_log:
+            torch.save(return_lists, os.path.join(args.test_dir, args.save_flag, "results_dump.pt"))
+    else:
+        if not args.synthetic:
+            raise NotImplementedError("dataset loaders (datasets/*.py) are out of scope: use --synthetic for constrained runs, or "
+                                      "call evaluate_constraint with your own DataLoader")
+        Constraint = get_constraint_function(args, d.image_size, d.channels)
+        loader = synthetic_val_loader(args, (d.channels, d.image_size, d.image_size), args.sample_size)
+        log_dict, _ = evaluate_constraint(
+            experiment, loader, Constraint, images_dir, args.sample_size, norm_init_noise=args.norm_init_noise,
+            style=args.sigma_type, sampling=args.sampling, norm_eps=args.norm_eps, refine_prior_sigma=args.refine_sigma,
+            prior_xt=args.prior_xt, sigma_estimate_rate=args.sigma_estimate_rate, return_log=False, max_T=args.max_T,
+            sigma_pred_threshold=args.sigma_pred_threshold, new_eta=args.new_eta, recal_sigma_prev=args.recal_sigma_prev,
+            save_images=bool(args.save_png))
     with open(os.path.join(args.test_dir, args.save_flag, "results.json"), "w") as f:
         json.dump(log_dict, f)
+    log_dict.pop("full_log", None)
     print(log_dict)
     print("evaluate done")
     return log_dict

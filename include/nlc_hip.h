@@ -164,12 +164,51 @@ int nlc_refine_sigma(const float* sumsq, float sqrt_dim, float norm_max, float n
                      float* sigma_t, float* sigma_prev, float* t, float* c_in,
                      int B, void* stream);
 
+/* General form of nlc_refine_sigma: per-sample scheduled inputs (projection_loop carries sigma_t and t per
+ * sample from step to step, image_sample.py:461-497) and continuous-t schedules.
+ *   sigma_in / t_in   : [B] per-sample scheduled values, or NULL -> the scalars sigma_sched / t_sched.  They may
+ *                       alias sigma_t / t (each sample is read before it is written).
+ *   prev_is_ratio     : sigma_prev[b] = raw_sigma[b] * sigma_prev_sched (recal_sigma_prev, image_sample.py:463-464)
+ *                       instead of the scalar sigma_prev_sched; raw_sigma is the value BEFORE the refine clamp.
+ *   t_slopes          : NULL -> discrete t = searchsorted_left(sigmas, sigma) (src/schedulers.py:185-190);
+ *                       else [n_sigmas-1] f32 slopes 1/(eps+sigmas[i+1]-sigmas[i]) -> continuous t by linear
+ *                       interpolation, t = i + slopes[i]*(sigma - sigmas[i]), i = clamp(searchsorted-1, 0, n-2)
+ *                       (sigma_to_t_interp, src/schedulers.py:210-220; src/torchinterp1d.py:10-154).
+ *   time_shift        : subtracted from every t when refine and min_b t > 0 (src/experiments.py:411-412). */
+typedef struct nlc_sigma_desc {
+    const float* sumsq;      /* [B] row sums of squares of xt (refine only) */
+    const float* sigma_in;   /* [B] or NULL */
+    const float* t_in;       /* [B] or NULL */
+    const float* sigmas;     /* [n_sigmas] ascending table */
+    const float* t_slopes;   /* [n_sigmas-1] or NULL */
+    float* sigma_t;          /* out [B] */
+    float* sigma_prev;       /* out [B] */
+    float* t;                /* out [B] */
+    float* c_in;             /* out [B] */
+    float sqrt_dim, norm_max, norm_min;
+    float sigma_sched, sigma_prev_sched, t_sched, time_shift;
+    int refine, prev_is_ratio, n_sigmas, B;
+} nlc_sigma_desc;
+int nlc_refine_sigma_ex(const nlc_sigma_desc* d, void* stream);
+
 /* NLC correction (src/experiments.py:424-431): sigma_hat = sigma_t*(1+r[b]),
  * sigma_prev_hat = sigma_hat*(sigma_prev/sigma_t) (skipped when partial != 0, style
- * 'pred_partial'), t = clamp(searchsorted_left(sigmas, sigma_hat),0,1000), c_in updated. */
-int nlc_sigma_correct(const float* r, int partial, const float* sigmas, int n_sigmas,
+ * 'pred_partial'), t = clamp(lookup(sigma_hat),0,1000) with the lookup of nlc_sigma_desc.t_slopes
+ * (NULL = discrete searchsorted_left), c_in updated. */
+int nlc_sigma_correct(const float* r, int partial, const float* sigmas, const float* t_slopes, int n_sigmas,
                       float* sigma_t, float* sigma_prev, float* t, float* c_in,
                       int B, void* stream);
+
+/* projection_loop's per-step sigma re-estimation (image_sample.py:485-497), in place on the per-sample state:
+ *   cur_norm = sqrt(sumsq[b])/sqrt_dim                       (sumsq of the NEW x_{t-1})
+ *   cur_dist = sqrt(cur_norm^2 + norm_max_sq - 2*cur_norm*norm_max*costheta + 1e-8)
+ *   sigma_t[b] <- term0 + r1*sigma_prev[b] + r2*sigma_t[b]*(cur_norm/last_norm[b]) + r3*cur_dist
+ *   t[b] <- lookup(sigma_t[b]) (not clamped here; the next step clamps) ; last_norm[b] <- cur_norm
+ * term0 = sigma_estimate_rate[0] * scheduled sigma_prev (a host scalar). */
+int nlc_proj_sigma(const float* sumsq, float sqrt_dim, float norm_max, float norm_max_sq, float costheta,
+                   float term0, float r1, float r2, float r3, const float* sigmas, const float* t_slopes,
+                   int n_sigmas, float* last_norm, float* sigma_t, const float* sigma_prev, float* t,
+                   int B, void* stream);
 
 /* s[b] = clamp(quantile_q(|x[b,:]|), 1, max_value) with torch.quantile's linear
  * interpolation and f32 rank arithmetic (src/experiments.py:190-199), exact radix select. */

@@ -310,6 +310,102 @@ def gen_inpaint(models):
          cfg=json.dumps(dict(res=res, steps=steps, seed=seed, B=B)))
 
 
+@torch.no_grad()
+def gen_project(models):
+    """continuous-t schedules (Interp1d), the sigma 'redesign' tail and image_sample.projection_loop,
+    all run from the reference's own code (projection_loop imported from /root/reference/image_sample.py; the inline
+    redesign block image_sample.py:788-800 is exec'd from the reference file's text, never copied here)."""
+    import textwrap
+    from functools import partial
+    for name, attrs in (("basicsr", {}), ("basicsr.metrics", {}), ("basicsr.metrics.psnr_ssim", dict(calculate_ssim=None)),
+                        ("datasets", dict(get_dataset=None))):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    import image_sample as RIS
+    from functions.svd_operators import Inpainting
+    from src.schedulers import get_sampler
+    from src.experiments import ImageExperiment
+    src = (REF / "image_sample.py").read_text().splitlines()
+    lo = next(i for i, l in enumerate(src) if l.strip().startswith("if args.redesign_sigma and args.max_T>args.num_timesteps"))
+    hi = next(i for i in range(lo, len(src)) if src[i].strip().startswith("sampler.to(args.device)"))
+    redesign_block = textwrap.dedent("\n".join(src[lo:hi]))
+
+    eps, sig, _ = models["simple_tiny"]
+    res, C, B, seed = 32, 3, 2, 1234
+    shape = (B, C, res, res)
+
+    def experiment(sch):
+        exp = ImageExperiment(eps, sch, batch_size=B, data_shape=(C, res, res), seed=seed, device="cpu", save_folder="/tmp")
+        exp.set_model(eps, sig, learn_epsvar=False)
+        exp.set_norm_maxmin(0.0, 54.63)
+        exp.set_clip_fn("clamp")
+        return exp
+
+    # (a) continuous-t denoise_loop, 'Linear' sigma spacing
+    sch = get_sampler("ddim", 1000, 10, sigma_style="Linear", start_sigma=100, end_sigma=0.01, sampler_var="fixedsmall", eta=0.0,
+                      continuous_t=True)
+    exp = experiment(sch)
+    x, logs = exp.denoise_loop(shape=shape, gen=exp.new_gen(), style="pred", norm_eps=True, refine_prior_sigma=True,
+                               return_log=True, chunk_size=1, sigma_pred_threshold=960)
+    save("cont_linear", x=x, x0_first=logs[3][0], timesteps=sch.timesteps, sampling_sigmas=sch.sampling_sigmas,
+         cfg=json.dumps(dict(steps=10, start_sigma=100, end_sigma=0.01, style="Linear", seed=seed, B=B, res=res)))
+
+    # (b) projection_loop on the same schedule: 4-way sigma blend + recal_sigma_prev
+    rate = [0.4, 0.3, 0.2, 0.1]
+    exp = experiment(sch)
+    x, logs = RIS.projection_loop(self=exp, shape=shape, gen=exp.new_gen(), style="pred", norm_eps=True, refine_prior_sigma=True,
+                                  return_log=True, chunk_size=1, sigma_estimate_rate=rate, sigma_pred_threshold=960,
+                                  recal_sigma_prev=True)
+    save("proj_linear", x=x, x0_first=logs[3][0], sigma_trace=torch.stack([s.reshape(-1) for s in logs[4][1:]]),
+         cfg=json.dumps(dict(rate=rate, recal=True, seed=seed, B=B, res=res)))
+    #     ... and a discrete-t schedule without recal (t by searchsorted on the blended sigma)
+    sch_d = get_sampler("ddim", 1000, 10, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    exp = experiment(sch_d)
+    rate_d = [0.5, 0.5, 0.0, 0.0]
+    x, logs = RIS.projection_loop(self=exp, shape=shape, gen=exp.new_gen(), style="pred_partial", norm_eps=True,
+                                  refine_prior_sigma=False, return_log=True, chunk_size=1, sigma_estimate_rate=rate_d,
+                                  sigma_pred_threshold=960, recal_sigma_prev=False)
+    save("proj_discrete", x=x, x0_first=logs[3][0], sigma_trace=torch.stack([s.reshape(-1) for s in logs[4][1:]]),
+         cfg=json.dumps(dict(rate=rate_d, recal=False, seed=seed, B=B, res=res)))
+
+    # (c) sigma redesign tail (image_sample.py:788-800) + projection with the inpainting constraint (paper's pred_proj)
+    args = argparse.Namespace(redesign_sigma=1, max_T=12, num_timesteps=8, cycle_size=2, min_sigma=0.01, max_sigma=0.05,
+                              sigma_gamma=0.7)
+    sampler = get_sampler("ddim", 1000, 8, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    exec(redesign_block, dict(args=args, sampler=sampler, np=np, torch=torch, print=lambda *a, **k: None))
+    g = torch.Generator().manual_seed(11)
+    missing_r = torch.randperm(res * res, generator=g)[: res * res // 2].long() * 3
+    missing = torch.cat([missing_r, missing_r + 1, missing_r + 2], dim=0)
+    op = Inpainting(C, res, missing, "cpu")
+    x_gt = torch.rand(B, C, res, res, generator=g) * 2 - 1
+    y = op.A(x_gt)
+
+    def affine_svd(x0_t, y, A, Ap):                                                      # image_sample.py:376-380
+        return x0_t - Ap(A(x0_t.reshape(x0_t.size(0), -1)) - y.reshape(y.size(0), -1)).reshape(*x0_t.size())
+
+    def loss(x, y):                                                                      # image_sample.py:325-333
+        return (torch.linalg.vector_norm(op.A(x) - y, ord=1, dim=1).cpu(),
+                torch.linalg.vector_norm(op.A_pinv(y).view(x.shape) - x, ord=1, dim=(1, 2, 3)).cpu())
+
+    rate_c = [0.0, 1.0, 0.0, 0.0]
+    # with the reference driver's stop_condition=0.0 the exact inpainting projection ends the run early (:515)
+    exp = experiment(sampler)
+    _, logs0 = RIS.projection_loop(self=exp, shape=shape, gen=exp.new_gen(), style="pred", norm_eps=True, refine_prior_sigma=True,
+                                   constrain_fn=partial(affine_svd, y=y, A=op.A, Ap=op.A_pinv), constrain_loss=partial(loss, y=y),
+                                   return_log=True, chunk_size=1, sigma_estimate_rate=rate_c, max_T=args.max_T,
+                                   stop_condition=0.0, sigma_pred_threshold=960, recal_sigma_prev=True)
+    exp = experiment(sampler)
+    x, logs = RIS.projection_loop(self=exp, shape=shape, gen=exp.new_gen(), style="pred", norm_eps=True, refine_prior_sigma=True,
+                                  constrain_fn=partial(affine_svd, y=y, A=op.A, Ap=op.A_pinv), constrain_loss=partial(loss, y=y),
+                                  return_log=True, chunk_size=1, sigma_estimate_rate=rate_c, max_T=args.max_T,
+                                  stop_condition=-1.0, sigma_pred_threshold=960, recal_sigma_prev=True)
+    save("proj_redesign", x=x, x0_first=logs[3][0], sigma_trace=torch.stack([s.reshape(-1) for s in logs[4][1:]]),
+         timesteps=sampler.timesteps, sampling_sigmas=sampler.sampling_sigmas, missing=missing, x_gt=x_gt, y=y,
+         n_steps=len(logs[1]), n_steps_stop0=len(logs0[1]), const_loss=torch.stack(logs[5]), x0_last=logs[3][-1], x0_sub=torch.stack(logs[3])[..., ::4, ::4],
+         cfg=json.dumps(dict(rate=rate_c, recal=True, seed=seed, B=B, res=res, **vars(args))))
+
+
 def main():
     _stub_missing_modules()
     torch.manual_seed(0)
@@ -319,6 +415,7 @@ def main():
     gen_sched()
     gen_loops(models)
     gen_inpaint(models)
+    gen_project(models)
 
 
 if __name__ == "__main__":

@@ -79,3 +79,25 @@ def test_no_cpu_fallback():
         eps(torch.zeros(1, 3, 32, 32), torch.zeros(1))
     with pytest.raises(NlcError):
         sig(torch.zeros(1, 64, 8, 8))
+
+
+def test_continuous_t_and_redesigned_schedules_match_reference():
+    """Host-side schedule construction for SURVEY §8 f-2 (continuous t by Interp1d; the sigma-redesign tail)."""
+    import json
+    import numpy as np
+    from diffusion_nlc_amd.schedulers import get_sampler, redesign_sigma
+    from tests.util import load_npz
+    g = load_npz("cont_linear")
+    s = get_sampler("ddim", 1000, 10, sigma_style="Linear", start_sigma=100, end_sigma=0.01, sampler_var="fixedsmall", eta=0.0,
+                    continuous_t=True)
+    assert s.continuous_t and s.timesteps.dtype == g["timesteps"].dtype
+    assert torch.equal(s.timesteps, g["timesteps"]) and torch.equal(s.sampling_sigmas, g["sampling_sigmas"])
+    assert s.device_t_slopes("cpu").shape == (999,)
+    g = load_npz("proj_redesign")
+    c = g["cfg"]
+    s = get_sampler("ddim", 1000, c["num_timesteps"], sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    assert s.device_t_slopes("cpu") is None
+    redesign_sigma(s, c["num_timesteps"], c["max_T"], c["cycle_size"], c["min_sigma"], c["max_sigma"], c["sigma_gamma"])
+    assert s.continuous_t and s.sampling_sigmas.dtype == g["sampling_sigmas"].dtype == torch.float64
+    assert torch.equal(s.sampling_sigmas, g["sampling_sigmas"])
+    assert torch.equal(s.timesteps, g["timesteps"])
