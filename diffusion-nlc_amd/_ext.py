@@ -107,6 +107,7 @@ SIGNATURES = {
     "nlc_scale_rows": (C.c_int, [_vp, _vp, _f, _vp, _i, _i64, _vp]),
     "nlc_cast_f64_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "nlc_row_sumsq_f64": (C.c_int, [_vp, _vp, _i, _i64, _vp]),
+    "nlc_row_cosine_f64": (C.c_int, [_vp, _vp, C.c_double, _vp, _i, _i64, _vp]),
     "nlc_edm_scalars": (C.c_int, [_vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "nlc_edm_eps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "nlc_f64_lincomb": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),

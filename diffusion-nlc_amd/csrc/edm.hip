@@ -30,6 +30,42 @@ __global__ __launch_bounds__(RT) void row_sumsq_f64_kernel(const double* __restr
     }
 }
 
+// torch.nn.CosineSimilarity(dim=1, eps) of two [B, D] f64 tensors (src/experiments.py:870,912-915; ATen
+// cosine_similarity: each operand is divided by max(||.||, eps) and the quotients are dotted; one workgroup per row,
+// two passes: norms, then the dot of the normalised rows).
+__global__ __launch_bounds__(RT) void row_cosine_f64_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                           double eps, double* __restrict__ out, int64_t D) {
+    __shared__ double sh[3][RT / 64];
+    __shared__ double s_na, s_nb;
+    const double* ra = a + (int64_t)blockIdx.x * D;
+    const double* rb = b + (int64_t)blockIdx.x * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    double aa = 0.0, bb = 0.0;
+    for (int64_t i = threadIdx.x; i < D; i += RT) { aa += ra[i] * ra[i]; bb += rb[i] * rb[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { aa += __shfl_xor(aa, o, 64); bb += __shfl_xor(bb, o, 64); }
+    if (l == 0) { sh[0][w] = aa; sh[1][w] = bb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int i = 0; i < RT / 64; ++i) { ta += sh[0][i]; tb += sh[1][i]; }
+        s_na = fmax(sqrt(ta), eps); s_nb = fmax(sqrt(tb), eps);
+    }
+    __syncthreads();
+    const double na = s_na, nb = s_nb;
+    double ab = 0.0;
+    for (int64_t i = threadIdx.x; i < D; i += RT) ab += (ra[i] / na) * (rb[i] / nb);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ab += __shfl_xor(ab, o, 64);
+    if (l == 0) sh[2][w] = ab;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < RT / 64; ++i) t += sh[2][i];
+        out[blockIdx.x] = t;
+    }
+}
+
 // encode_edm / pred_edm scalars (src/experiments.py:779-783,790-797): sigma is cast to f32 first.
 __global__ void edm_scalars_kernel(const double* __restrict__ sigma, float sigma_data, float* __restrict__ c_in,
                                    float* __restrict__ c_noise, float* __restrict__ c_skip, float* __restrict__ c_out, int B) {
@@ -91,6 +127,13 @@ extern "C" int nlc_row_sumsq_f64(const double* x, double* sumsq, int B, int64_t 
     NLC_REQUIRE(x && sumsq && B > 0 && D > 0, "nlc_row_sumsq_f64: bad arguments");
     hipLaunchKernelGGL(row_sumsq_f64_kernel, dim3(B), dim3(RT), 0, (hipStream_t)stream, x, sumsq, D);
     NLC_CHECK_LAUNCH("nlc_row_sumsq_f64");
+    return NLC_OK;
+}
+
+extern "C" int nlc_row_cosine_f64(const double* a, const double* b, double eps, double* out, int B, int64_t D, void* stream) {
+    NLC_REQUIRE(a && b && out && B > 0 && D > 0 && eps >= 0.0, "nlc_row_cosine_f64: bad arguments");
+    hipLaunchKernelGGL(row_cosine_f64_kernel, dim3(B), dim3(RT), 0, (hipStream_t)stream, a, b, eps, out, D);
+    NLC_CHECK_LAUNCH("nlc_row_cosine_f64");
     return NLC_OK;
 }
 

@@ -161,8 +161,6 @@ class EDMImageExperiment(ImageExperiment):
         else:
             raise NotImplementedError
         steps = torch.cat([torch.as_tensor(steps), torch.zeros_like(steps[:1])])          # host f64 schedule
-        if eps_scale is None:
-            raise NotImplementedError("cosine-similarity eps scaling (eps_scale=None, :912-916) is a SURVEY §8 'next' row (f-3)")
         one = torch.ones(B, device=self.device, dtype=torch.float64)
         x_next = lincomb(latents.to(torch.float64).contiguous(), one * float(steps[0]))
         for i, (s_cur, s_next) in enumerate(zip(steps[:-1], steps[1:])):
@@ -170,8 +168,11 @@ class EDMImageExperiment(ImageExperiment):
             s_cur, s_next0 = float(s_cur), float(s_next)
             gamma = min(self.S_churn / n, np.sqrt(2) - 1) if self.S_min <= s_cur <= self.S_max else 0
             s_hat0 = s_cur + gamma * s_cur
-            if gamma > 0:                                                      # churn noise, host-drawn (:880)
-                z = torch.randn(x_cur.shape, dtype=torch.float64).to(self.device)
+            # churn noise (:880): the reference draws randn_like on EVERY step from the global generator; with
+            # S_churn > 0 the draw is kept on every step so the stream stays aligned when S_min/S_max gate gamma
+            z = torch.randn(x_cur.shape, dtype=torch.float64) if self.S_churn > 0 else None
+            if gamma > 0:
+                z = z.to(self.device)
                 x_hat = lincomb(x_cur, one, z, one * (math.sqrt(s_hat0 ** 2 - s_cur ** 2) * self.S_noise))
             else:
                 x_hat = x_cur                                                  # + 0 * randn_like: exact no-op
@@ -198,7 +199,13 @@ class EDMImageExperiment(ImageExperiment):
                 new_eps = lincomb(eps, one * eps_ratio, eps_next, one * (1 - eps_ratio))
                 if norm_combine:
                     new_eps = self._normalize(new_eps)
-                new_eps = lincomb(new_eps, one / eps_scale)
+                if eps_scale is not None:
+                    new_eps = lincomb(new_eps, one / eps_scale)
+                else:                                                          # cosine-similarity scaling (:911-916)
+                    cs = torch.empty(B, device=self.device, dtype=torch.float64)
+                    check(_ext.load().nlc_row_cosine_f64(new_eps.data_ptr(), eps.data_ptr(), 1e-6, cs.data_ptr(), B,
+                                                         new_eps.numel() // B, _s()), "nlc_row_cosine_f64")
+                    new_eps = lincomb(new_eps, cs)
                 x_next = lincomb(x_hat, one, new_eps, s_nxt - s_hat)
         return x_next
 

@@ -258,6 +258,11 @@ int nlc_scale_rows(const float* x, const float* scale /*[B]*/, float scalar, flo
 int nlc_cast_f64_f32(const double* x, float* out, int64_t n, void* stream);
 /* sumsq[b] = sum_d x[b,d]^2 in f64            vector_norm on the f64 state, :808,842 */
 int nlc_row_sumsq_f64(const double* x, double* sumsq, int B, int64_t D, void* stream);
+
+/* out[b] = cosine_similarity(a[b,:], b[b,:]) = sum_d (a/max(||a||,eps)) * (b/max(||b||,eps)) in f64:
+ * torch.nn.CosineSimilarity(dim=1, eps=1e-6) of the Heun step's eps_scale=None branch
+ * (src/experiments.py:870,912-915). */
+int nlc_row_cosine_f64(const double* a, const double* b, double eps, double* out, int B, int64_t D, void* stream);
 /* preconditioning scalars from sigma[b] cast to f32 (:790-797):
  *   c_skip = sd^2/(s^2+sd^2), c_out = s*sd/sqrt(s^2+sd^2), c_in = 1/sqrt(sd^2+s^2), c_noise = ln(s)/4 */
 int nlc_edm_scalars(const double* sigma, float sigma_data, float* c_in, float* c_noise,

@@ -251,10 +251,14 @@ def gen_loops(models):
 
     # EDM / Heun + NLC (BASELINE config 3, reduced)
     eps, sig, _ = models["edm_tiny"]
-    for name, style, second, norm in (("loop_edm_pred", "pred_partial,pred", True, "00"), ("loop_edm_base", "base,base", True, "00"),
-                                      ("loop_edm_euler", "pred,pred", False, "10")):
+    for name, style, second, norm, scale, churn in (("loop_edm_pred", "pred_partial,pred", True, "00", 1.0, 0.0),
+                                                    ("loop_edm_base", "base,base", True, "00", 1.0, 0.0),
+                                                    ("loop_edm_euler", "pred,pred", False, "10", 1.0, 0.0),
+                                                    # f-3: cosine-similarity eps scaling; pred_partial3 / pred_sigma + S_churn
+                                                    ("loop_edm_cos", "pred,pred", True, "01", None, 0.0),
+                                                    ("loop_edm_p3", "pred_partial3,pred_sigma", True, "00", 1.0, 2.0)):
         exp = EDMImageExperiment(eps, None, batch_size=2, data_shape=(3, 32, 32), seed=0, device="cpu", save_folder="/tmp",
-                                 num_timesteps=6)
+                                 num_timesteps=6, S_churn=churn)
         exp.set_model(eps, sig, learn_epsvar=False)
         exp.set_norm_maxmin(0.0, 54.63)
         lat = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(77))
@@ -264,8 +268,9 @@ def gen_loops(models):
                 return lat
         torch.manual_seed(3)
         x = exp.edm_sampler(shape=(2, 3, 32, 32), gen=G(), style=style, norm_eps=norm + "0", refine_prior_sigma=False,
-                            eps_ratio=0.5, eps_scale=1.0, use_second_order=second)
-        save(name, latents=lat, x=x, cfg=json.dumps(dict(style=style, second=second, norm_eps=norm + "0", steps=6)))
+                            eps_ratio=0.5, eps_scale=scale, use_second_order=second)
+        save(name, latents=lat, x=x, cfg=json.dumps(dict(style=style, second=second, norm_eps=norm + "0", steps=6,
+                                                         eps_scale=scale, S_churn=churn)))
 
 
 @torch.no_grad()

@@ -77,18 +77,20 @@ def test_loop_without_logging_is_identical():
     assert torch.equal(x1, x2) and logs[1] == []
 
 
-@pytest.mark.parametrize("name", ["loop_edm_pred", "loop_edm_base", "loop_edm_euler"])
+@pytest.mark.parametrize("name", ["loop_edm_pred", "loop_edm_base", "loop_edm_euler", "loop_edm_cos", "loop_edm_p3"])
 def test_f32_edm_sampler_matches_reference(name):
     """EDM / Heun + NLC (float64 state, float32 network) vs the reference's own edm_sampler output."""
     from diffusion_nlc_amd.experiments import EDMImageExperiment
     g = load_npz(name)
     c = g["cfg"]
     eps, sig = _models("edm_tiny", torch.float32)
-    exp = EDMImageExperiment(eps, None, batch_size=2, data_shape=(3, 32, 32), seed=0, device="cuda:0", num_timesteps=c["steps"])
+    exp = EDMImageExperiment(eps, None, batch_size=2, data_shape=(3, 32, 32), seed=0, device="cuda:0", num_timesteps=c["steps"],
+                             S_churn=c["S_churn"])
     exp.set_model(eps, sig, learn_epsvar=False)
     exp.set_norm_maxmin(0.0, 54.63)
+    torch.manual_seed(3)                                  # the churn noise comes from the global host generator (:880)
     x = exp.edm_sampler(shape=(2, 3, 32, 32), latents=g["latents"], style=c["style"], norm_eps=c["norm_eps"],
-                        eps_ratio=0.5, eps_scale=1.0, use_second_order=c["second"])
+                        eps_ratio=0.5, eps_scale=c["eps_scale"], use_second_order=c["second"])
     assert x.dtype == torch.float64
     ex = max_err(x.cpu(), g["x"])
     print(f"{name}: f32-net / f64-state L-inf {ex:.2e}")

@@ -109,15 +109,16 @@ def test_denoise_loop_matches_reference(name):
     assert max_err(x, g["x"]) < 1e-4, max_err(x, g["x"])
 
 
-@pytest.mark.parametrize("name", ["loop_edm_pred", "loop_edm_base", "loop_edm_euler"])
+@pytest.mark.parametrize("name", ["loop_edm_pred", "loop_edm_base", "loop_edm_euler", "loop_edm_cos", "loop_edm_p3"])
 def test_edm_sampler_matches_reference(name):
     from oracle.loop import EdmOracle
     g = load_npz(name)
     c = g["cfg"]
     eps_fn, enc_fn, sig_fn, _ = oracle_nets("edm_tiny")
-    o = EdmOracle(eps_fn, enc_fn, sig_fn, (3, 32, 32), num_timesteps=c["steps"], norm_min=0.0, norm_max=54.63)
+    o = EdmOracle(eps_fn, enc_fn, sig_fn, (3, 32, 32), num_timesteps=c["steps"], norm_min=0.0, norm_max=54.63,
+                  S_churn=c["S_churn"])
     torch.manual_seed(3)
-    x = o.edm_sampler(g["latents"], style=c["style"], norm_eps=c["norm_eps"], eps_ratio=0.5, eps_scale=1.0,
+    x = o.edm_sampler(g["latents"], style=c["style"], norm_eps=c["norm_eps"], eps_ratio=0.5, eps_scale=c["eps_scale"],
                       use_second_order=c["second"])
     assert x.dtype == torch.float64
     assert max_err(x, g["x"]) < 1e-4, max_err(x, g["x"])
