@@ -14,6 +14,12 @@
 //   (register double buffering across the barrier - with one barrier per k-step and all waves in lockstep
 //   the MFMA pipe otherwise idles through every fragment-read burst).  One counted s_waitcnt vmcnt(N) +
 //   barrier per k-step.  All DMA is issued from inline asm (see conv_fast.hip for why).
+//   PERSISTENT: one workgroup per CU walks a list of tiles; the halo / weight DMA streams run straight across tile
+//   boundaries (the next tile's first halo + weights land under the current tile's last k-steps) and the epilogue
+//   writes the accumulators to global memory straight from registers (MFMA operands swapped so that a lane holds
+//   16 consecutive channels of one pixel) - no LDS transpose, no barrier, asynchronous stores.  Before this a
+//   workgroup paid ~45 % of its time in the per-tile prologue + LDS-staged epilogue with nothing to overlap them
+//   (1 workgroup per CU).
 //   Rows are XOR-swizzled chunk ^ (row & 7): conflict-free ds_read_b128 for 16 consecutive rows at ANY
 //   alignment, which the tap shifts need (brute-forced).
 #include "common.h"
@@ -35,7 +41,6 @@ constexpr int NBST = 4;                         // weight stages (3 steps ahead)
 constexpr int NA = 6, NB = 2;                   // DMA wave-instructions per wave: per halo / per weight tile
 constexpr int SCRATCH = 8 * 8 * KB_BYTES;       // landing zone of the padding DMA instructions (8 KiB)
 constexpr int HALO_LDS = 2 * A_STAGE + NBST * B_STAGE + SCRATCH;   // 157,696 B
-constexpr int EPI_LD = BN + 4;
 
 template <typename T> struct MmaH;
 template <> struct MmaH<bf16_raw> {
@@ -64,10 +69,36 @@ __device__ __forceinline__ void glds16h(const void* gptr, unsigned lds_base) {
                  "global_load_lds_dwordx4 %1, off\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gptr), "s"(lds_base)
+                 : "v"(gptr), "s"(__builtin_amdgcn_readfirstlane(lds_base))   // wave-uniform by construction
+                 : "memory");
+}
+// SGPR-base form: address = sbase (uniform, 64-bit) + voff (per lane, 32-bit unsigned) - no per-lane 64-bit address
+// arithmetic in the k-loop (the VGPR-address form cost ~12 VALU incl. quarter-rate 64-bit multiplies per weight DMA)
+__device__ __forceinline__ void glds16h_s(unsigned voff, const void* sbase, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(__builtin_amdgcn_readfirstlane(lds_base)), "s"(sbase)
                  : "memory");
 }
 template <int N> __device__ __forceinline__ void dma_wait_h() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct TileH { int tb, y0, x0, n0; };
+
+// ---- diagnostic build only (-DHALO_STAMP): s_memtime stamps around the phases of ONE k-step (tile 1, cb 1, tap 4) of
+//      workgroup 0, per wave; read back with nlc_debug_halo_stamps.  No stamp executes in the normal build.
+#ifdef HALO_STAMP
+__device__ unsigned long long g_halo_stamps[8][8];
+#define STAMP(i) do { if (stamp_on && tap == 4) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define STAMP_FLUSH() do { if (stamp_on && tap == 4 && lane == 0) { for (int q_ = 0; q_ < 8; ++q_) g_halo_stamps[wave][q_] = st[q_]; } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#define STAMP_FLUSH() do {} while (0)
+#endif
 
 template <typename T>
 __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
@@ -76,20 +107,28 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     constexpr int KBE = MmaH<T>::KBE;
     constexpr int ES = (int)sizeof(T);
 
+    // ---- persistent tile schedule: XCD x (= workgroup id & 7, the dispatcher's round-robin) owns a contiguous
+    //      chunk of the tile list (N-tile fastest, so neighbours in time share the halo and the weights in that
+    //      XCD's L2); the workgroups of an XCD walk their chunk with stride (workgroups per XCD).
     const int tiles_x = p.Win / PATCH, tiles_y = p.Hin / PATCH;
-    const int MTH = p.B * tiles_y * tiles_x;
-    const int nblk = MTH * p.NT;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int mt = bid / p.NT, nt = bid - mt * p.NT;
-    const int tb = mt / (tiles_y * tiles_x);
-    const int trem = mt - tb * tiles_y * tiles_x;
-    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    const int y0 = ty * PATCH, x0 = tx * PATCH, n0 = nt * BN;
+    const int nblk = p.B * tiles_y * tiles_x * p.NT;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+    const int gx = (G - xcd + 7) >> 3;
+    const int cq = nblk >> 3, cr = nblk & 7;
+    const int chunk_start = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int chunk_len = cq + (xcd < cr ? 1 : 0);
+    auto decode = [&](int tl) {
+        const int id = chunk_start + tl;
+        const int mt = id / p.NT, nt = id - mt * p.NT;
+        const int tb = mt / (tiles_y * tiles_x);
+        const int trem = mt - tb * tiles_y * tiles_x;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        return TileH{tb, ty * PATCH, tx * PATCH, nt * BN};
+    };
+    int tl = wi;
+    if (tl >= chunk_len) return;                     // workgroup-uniform
+    TileH cur = decode(tl);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -102,55 +141,60 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     const int ncb = p.Cin_pad / KBE;
     const int nk = ncb * 9;
 
-    // ---- this lane's (up to) 6 halo rows: DMA instruction q = wave + 8 j covers LDS rows 8q .. 8q+7; q >= 41 is padding
-    int hpix[NA], hchunk[NA];
+    // ---- this lane's (up to) 6 halo rows: DMA instruction q = wave + 8 j covers LDS rows 8q .. 8q+7; q >= 41 is padding.
+    //      (hy, hx) never change; the source pixel is recomputed per tile.  Source-side swizzle: R & 7 == lrow.
+    int hpix[NA];
     unsigned hvalid = 0;
+    const int hchunk = lslot ^ lrow;
+    auto halo_addr = [&](const TileH& t) {           // once per tile: (hy, hx) of this lane's rows are recomputed, not kept
+        hvalid = 0;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        const int R = (wave + 8 * j) * 8 + lrow;
-        const int hy = R / HALO, hx = R - hy * HALO;
-        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-        const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-        hpix[j] = ok ? (tb * p.Hin + iy) * p.Win + ix : 0;
-        hchunk[j] = lslot ^ (R & 7);                 // source-side swizzle
-        hvalid |= (ok ? 1u : 0u) << j;
-    }
+        for (int j = 0; j < NA; ++j) {
+            const int R = (wave + 8 * j) * 8 + lrow;  // DMA instruction q = wave + 8 j covers LDS rows 8q .. 8q+7; q >= 41 is padding
+            const int hy = R / HALO, hx = R - hy * HALO;
+            const int iy = t.y0 + hy - 1, ix = t.x0 + hx - 1;
+            const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            hpix[j] = ok ? (t.tb * p.Hin + iy) * p.Win + ix : 0;
+            hvalid |= (ok ? 1u : 0u) << j;
+        }
+    };
     const int64_t wrow = (int64_t)9 * p.Cin_pad * ES;
     const char* zero = reinterpret_cast<const char*>(g_zero_page_h);
 
-    auto issue_A = [&](int cb) {
-        const unsigned base = lds0 + (cb & 1) * A_STAGE + wave * 8 * KB_BYTES;
+    auto issue_A = [&](int cb, int astage) {
+        const unsigned base = lds0 + astage * A_STAGE + wave * 8 * KB_BYTES;
+        const int cch = cb * KBE + hchunk * PER;
+        const char* src; int C, ch;
+        if (cch < p.C0) { src = p.x0; C = p.C0; ch = cch; } else { src = p.x1; C = p.C1; ch = cch - p.C0; }
+        const bool chok = cch < p.Ctot;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int cch = cb * KBE + hchunk[j] * PER;
-            const char* src; int C, ch;
-            if (cch < p.C0) { src = p.x0; C = p.C0; ch = cch; } else { src = p.x1; C = p.C1; ch = cch - p.C0; }
-            const bool ok = ((hvalid >> j) & 1u) && cch < p.Ctot;
+            const bool ok = ((hvalid >> j) & 1u) && chok;
             const char* ptr = ok ? src + ((int64_t)hpix[j] * C + ch) * ES : zero;
             const bool real = (wave + 8 * j) < A_INSTR;                       // wave-uniform
             glds16h(ptr, real ? base + j * 64 * KB_BYTES : ldsScratch);      // every wave issues exactly NA instructions
         }
     };
-    // weights of k-step kt (= cb*9 + tap) into a B stage; DMA instruction q = wave + 8 j covers rows 8q..8q+7
-    auto issue_B = [&](int kt, int bstage) {
+    unsigned woff[NB];                               // per-lane byte offset of this lane's weight row + chunk (constant)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (wave + 8 * j) * 8 + lrow;   // DMA instruction q = wave + 8 j covers LDS rows 8q..8q+7
+        const int r = row & 15, jj = (row >> 4) & 3;
+        const int ch = (row & 64) + (r >> 2) * 16 + jj * 4 + (r & 3);
+        const int gchunk = lslot ^ (row & 7);
+        woff[j] = (unsigned)((int64_t)ch * wrow + (int64_t)gchunk * PER * ES);      // < 128 * 9 * Cin_pad * ES: fits 32 bits
+    }
+    auto issue_B = [&](int n0, int kt, int bstage) {
         const int cb = kt / 9, tap = kt - cb * 9;
         const unsigned base = ldsB + bstage * B_STAGE + wave * 8 * KB_BYTES;
+        const char* sb = p.w + (int64_t)n0 * wrow + ((int64_t)tap * p.Cin_pad + cb * KBE) * ES;     // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int row = (wave + 8 * j) * 8 + lrow;
-            const int gchunk = lslot ^ (row & 7);
-            const char* ptr = p.w + (int64_t)(n0 + row) * wrow + ((int64_t)tap * p.Cin_pad + cb * KBE + gchunk * PER) * ES;
-            glds16h(ptr, base + j * 64 * KB_BYTES);
-        }
+        for (int j = 0; j < NB; ++j) glds16h_s(woff[j], sb, base + j * 64 * KB_BYTES);
     };
 
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
     f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int a_lane = wm * 4 * HALO + fr;           // halo row of (patch row wm*4, patch col fr) for tap (0,0)
     const int b_lane = wn * 64 + fr;
 
@@ -159,15 +203,13 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // With the taps unrolled at compile time the k-loop then carries no address arithmetic beyond one
     // add of the stage base per read (measured: the runtime-tap version spent more VALU issue cycles on
     // addresses than the MFMAs took).
-    int aoff[6][3][2], boff[2];
+    // Only the k-half 0 offsets are kept (18 + 1 registers): chunk (4 + fq) ^ r == (fq ^ r) ^ 4, so half 1 is "^ 64".
+    int aoff[6][3], boff;
 #pragma unroll
     for (int yy = 0; yy < 6; ++yy)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) aoff[yy][s][kk] = hoff(a_lane + yy * HALO + s, kk * 4 + fq);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) boff[kk] = hoff(b_lane, kk * 4 + fq);     // + j*16 rows = + j*2048 bytes (same row & 7)
+        for (int s = 0; s < 3; ++s) aoff[yy][s] = hoff(a_lane + yy * HALO + s, fq);
+    boff = hoff(b_lane, fq);                         // + j*16 rows = + j*2048 bytes (same row & 7)
 
     // fragment sets (register double buffer)
     uint4 fa0[4], fb0[4], fa1[4], fb1[4];
@@ -175,156 +217,237 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         constexpr int tap = decltype(tap_c)::value, kk = decltype(kk_c)::value;
         constexpr int r = tap / 3, s = tap % 3;
         const char* As = smem + astage * A_STAGE;
-        const char* Bs = smemB + bstage * B_STAGE + boff[kk];
+        const char* Bs = smemB + bstage * B_STAGE + (boff ^ (kk * 64));
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + j * 16 * KB_BYTES);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + aoff[i + r][s][kk]);
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + (aoff[i + r][s] ^ (kk * 64)));
     };
+    // operands swapped: D[m = channel][n = pixel]; lane (fr, fq) holds pixel fr, channels fq*4 + reg of MFMA tile j
     auto mma16 = [&](const uint4 (&fa)[4], const uint4 (&fb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) MmaH<T>::run(fa[i], fb[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) MmaH<T>::run(fb[j], fa[i], acc[i][j]);
     };
 
-    // ---- prologue: halo of block 0, weights of steps 0..2
-    issue_A(0);
-    issue_B(0, 0);
-    issue_B(1, 1);
-    issue_B(2, 2);
+    // ---- epilogue straight from registers: lane (fr, fq) of wave (wm, wn) holds, for patch row wm*4 + i and
+    //      column fr, the 16 consecutive output channels n0 + wn*64 + fq*16 + [0, 16)  (acc[i][j][reg] -> j*4 + reg).
+    //      bias + embedding are folded into the accumulators' INITIAL value (loaded for the next tile while the
+    //      current one is being stored), the residual chunks are all requested before the first one is used.
+    const int HWo = p.Hin * p.Win;
+    const bool vec_ok = (p.Cout % PER) == 0;
+    // bf16: bias + embedding are folded into the accumulators' initial value.  f32 (the parity path) keeps the
+    // reference's order instead - conv sum, then + bias, then + embedding, then + residual - so that it rounds like
+    // F.conv2d(x, w, b) + emb + res does; there the accumulators start at zero.
+    constexpr bool FOLD = sizeof(T) == 2;
+    auto load_cadd = [&](const TileH& t, float (&cadd)[16]) {
+        const int n = t.n0 + wn * 64 + fq * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool okc = n + k < p.Cout;
+            float v = (p.bias && okc) ? p.bias[n + k] : 0.f;
+            if (p.emb && okc) v += p.emb[(int64_t)t.tb * p.emb_stride + n + k];
+            cadd[k] = FOLD ? v : 0.f;
+        }
+    };
+    auto init_acc = [&](const float (&cadd)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cadd[j * 4], cadd[j * 4 + 1], cadd[j * 4 + 2], cadd[j * 4 + 3]};
+    };
+    auto epilogue = [&](const TileH& t, const TileH& nx) {
+        float cnext[16];
+        load_cadd(nx, cnext);                        // in flight while this tile is stored
+        const int n = t.n0 + wn * 64 + fq * 16;
+        if (n < p.Cout) {
+            const bool full = vec_ok && (n + 16 <= p.Cout);
+            constexpr int NCH = 16 / PER;
+            int64_t mrow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mrow[i] = ((int64_t)t.tb * p.Hin + t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
+            constexpr bool HOIST = NCH <= 2;         // bf16: all 8 residual chunks in flight at once (f32 would spill)
+            uint4 rres[HOIST ? 4 : 1][NCH];
+            if (HOIST && p.res && full) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        rres[HOIST ? i : 0][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + mrow[i] * p.Cout + n + c * PER);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = mrow[i];
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg];
+                if constexpr (!FOLD) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool okc = n + k < p.Cout;
+                        if (p.bias && okc) v[k] += p.bias[n + k];
+                        if (p.emb && okc) v[k] += p.emb[(int64_t)t.tb * p.emb_stride + n + k];
+                    }
+                }
+                if (p.res) {
+                    if (full) {
+                        if (!HOIST) {
+#pragma unroll
+                            for (int c = 0; c < NCH; ++c)
+                                rres[0][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + m * p.Cout + n + c * PER);
+                        }
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            float rr[PER];
+                            chunk_to_f32<T>(rres[HOIST ? i : 0][c], rr);
+#pragma unroll
+                            for (int k = 0; k < PER; ++k) v[c * PER + k] += rr[k];
+                        }
+                    } else {
+                        const T* rp = reinterpret_cast<const T*>(p.res) + m * p.Cout + n;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) if (n + k < p.Cout) v[k] += ElemTraits<T>::load(rp + k);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = apply_act(v[k] * p.out_scale, p.act);
+                if (p.out_mode == NLC_OUT_NHWC) {
+                    T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
+                    if (full) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(op + c * PER) = f32_to_chunk<T>(v + c * PER);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
+                    }
+                } else {
+                    const int64_t rem = (int64_t)(t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (n + k < p.Cout) reinterpret_cast<float*>(p.out)[((int64_t)t.tb * p.Cout + n + k) * HWo + rem] = v[k];
+                }
+            }
+        }
+        init_acc(cnext);
+    };
+
+    // ---- prologue (first tile only): halo of block 0, weights of steps 0..2
+    {
+        float c0[16];
+        load_cadd(cur, c0);
+        init_acc(c0);
+    }
+    halo_addr(cur);
+    issue_A(0, 0);
+    issue_B(cur.n0, 0, 0);
+    issue_B(cur.n0, min(1, nk - 1), 1);
+    issue_B(cur.n0, min(2, nk - 1), 2);
     dma_wait_h<NB>();                                // halo 0 + weights 0,1 landed (weights 2 may fly)
     __syncthreads();
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     load_frags(fa0, fb0, 0, 0, K0{}, K0{});
 
-    int kt = 0, bcur = 0;
-    for (int cb = 0; cb < ncb; ++cb) {
-        const bool more_cb = cb + 1 < ncb;
-        auto step = [&](auto tap_c) {
-            constexpr int tap = decltype(tap_c)::value;
-            const int bnext = (bcur + 1) & 3;
-            // Straight-line body (no data-dependent branches, so the compiler can software-pipeline it):
-            // past the end the weight DMA simply re-fetches the last tile into a free stage and the
-            // fragment prefetch reads stale-but-valid LDS; neither result is used.
-            issue_B(min(kt + 3, nk - 1), (bcur + 3) & 3);
-            if constexpr (tap == 0) { if (more_cb) issue_A(cb + 1); }      // AFTER the weights: they are needed first
-            // kk = 0: read this step's second half while the first half is in the MFMA pipe
-            // sched_barrier: keep "issue the NEXT fragments' LDS reads, THEN run the current MFMA cluster" - left
-            // alone hipcc sinks each read next to its first use and the LDS latency is exposed twice per step
-            // with every wave of the workgroup in the same phase (SQ_WAIT_ANY 51 %, MFMA busy 35 %).
-            load_frags(fa1, fb1, cb & 1, bcur, tap_c, K1{});
-            mma16(fa0, fb0);
-            // kk = 1: read the NEXT step's first half (its weights were published by the previous barrier;
-            //         the next halo, if tap == 8, landed by the end of tap 2)
-            {
+    // (Tried and measured slower on this kernel, 1.18 vs 1.12 ms on 256->256 @256^2: running SIMD partner waves in
+    //  complementary orders by giving waves 0-3 / 4-7 their barrier at different points of one instruction stream.)
+    constexpr int wdist = 3;                         // weight tiles run 3 k-steps ahead
+    int bcur = 0, hs = 0;                            // weight stage / halo stage of the current k-step (run across tiles)
+    for (;;) {
+        const bool has_next = tl + gx < chunk_len;
+        const TileH nxt = has_next ? decode(tl + gx) : cur;
+        int kt = 0;
+        for (int cb = 0; cb < ncb; ++cb) {
+            const bool last_cb = cb + 1 == ncb;
+            const bool more = !last_cb || has_next;  // a halo follows this one in the stream
+#ifdef HALO_STAMP
+            const bool stamp_on = blockIdx.x == 0 && tl == wi + gx && cb == 1;
+            unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+            auto step = [&](auto tap_c) {
+                constexpr int tap = decltype(tap_c)::value;
+                const int bnext = (bcur + 1) & 3;
                 constexpr int ntap = tap == 8 ? 0 : tap + 1;
-                const int nast = tap == 8 ? (cb + 1) & 1 : cb & 1;
-                load_frags(fa0, fb0, nast, bnext, std::integral_constant<int, ntap>{}, K0{});
-            }
-            mma16(fa1, fb1);
-            // retire weights kt+2; instructions younger than them may stay in flight:
-            // this step's weights kt+3 (NB) and a halo issued at this step (tap 0) or the previous one (tap 1)
-            if constexpr (tap <= 1) { if (more_cb) dma_wait_h<NB + NA>(); else dma_wait_h<NB>(); }
-            else dma_wait_h<NB>();
-            __syncthreads();
-            bcur = bnext;
-            ++kt;
-        };
-        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-    }
-
-    dma_wait_h<0>();          // the redundant tail fetches
-
-    // ---- epilogue: ONE pass - all 8 waves drop their 64x64 accumulators into an f32 LDS image
-    //      [256][EPI_LD] (132 KiB; every stage is free now), then all 512 threads apply bias / embedding /
-    //      residual / activation and store 16-byte chunks of contiguous channels.
-    const int HWo = p.Hin * p.Win;
-    float* epi = reinterpret_cast<float*>(smem);
-    const bool vec_ok = (p.Cout % PER) == 0;
-    {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    epi[(wm * 64 + i * 16 + fq * 4 + reg) * EPI_LD + wn * 64 + j * 16 + fr] = acc[i][j][reg];
-        __syncthreads();
-        // each thread owns ONE 16-byte column chunk (cc) for 256*CPR/HT rows: per-column terms are loaded once,
-        // the row loop is unrolled so the LDS reads / residual loads / stores of several rows are in flight together
-        constexpr int CPR = BN / PER;
-        constexpr int RSTEP = HT / CPR, NIT = 256 / RSTEP;
-        const int cc = tid % CPR, row0 = tid / CPR;
-        const int n = n0 + cc * PER;
-        if (n < p.Cout) {
-            const bool full = vec_ok && (n + PER <= p.Cout);
-            float cbias[PER], cemb[PER];
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const bool okc = n + k < p.Cout;
-                cbias[k] = (p.bias && okc) ? p.bias[n + k] : 0.f;
-                cemb[k] = (p.emb && okc) ? p.emb[(int64_t)tb * p.emb_stride + n + k] : 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int row = row0 + it * RSTEP;                    // row within the 256-pixel patch
-                const int py = row >> 4, px = row & 15;
-                const int64_t m = ((int64_t)tb * p.Hin + y0 + py) * p.Win + x0 + px;
-                float v[PER];
-#pragma unroll
-                for (int k = 0; k < PER; k += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(epi + row * EPI_LD + cc * PER + k);
-                    v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
-                }
-                float rr[PER];
-#pragma unroll
-                for (int k = 0; k < PER; ++k) rr[k] = 0.f;
-                if (p.res) {
-                    const T* rp = reinterpret_cast<const T*>(p.res) + m * p.Cout + n;
-                    if (full) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rp), rr);
-                    else {
-#pragma unroll
-                        for (int k = 0; k < PER; ++k) rr[k] = (n + k < p.Cout) ? ElemTraits<T>::load(rp + k) : 0.f;
+                const int nast = tap == 8 ? hs ^ 1 : hs;
+                // The weight / halo streams run straight across tile boundaries: the next tile's first halo and
+                // first three weight tiles are fetched under the current tile's last k-steps, so a workgroup pays the
+                // global-memory latency of a prologue once per launch, not once per tile.  Past the very end the
+                // weight DMA re-fetches the last tile into a free stage and the fragment prefetch reads
+                // stale-but-valid LDS; neither result is used (straight-line body, no data-dependent branches).
+                auto issue_dma = [&]() {
+                    const int k3 = kt + wdist;
+                    const bool wrap = k3 >= nk;
+                    issue_B(wrap ? nxt.n0 : cur.n0, wrap ? (has_next ? k3 - nk : nk - 1) : k3, (bcur + wdist) & 3);
+                    if constexpr (tap == 0) {
+                        if (more) {
+                            if (last_cb) halo_addr(nxt);
+                            issue_A(last_cb ? 0 : cb + 1, hs ^ 1);  // AFTER the weights: they are needed first
+                        }
                     }
-                }
+                };
+                STAMP(0);
+                issue_dma();
+                STAMP(1);
+                // Each half: 8 fragment reads for a LATER cluster + 16 MFMAs.  The sched_group_barrier pattern makes the
+                // backend interleave them as [1 ds_read, 2 MFMA] x 8 instead of "all reads, then all MFMAs": an MFMA holds
+                // the SIMD's issue port for 8 of its 16 cycles, so a read slipped into each gap costs ~nothing and a wave
+                // keeps the matrix pipe fed on its own (stamps: the read bursts used to cost 100-290 cycles per half with
+                // the pipe idle).
+                load_frags(fa1, fb1, hs, bcur, tap_c, K1{});      // this step's second half
+                mma16(fa0, fb0);
 #pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    float x = v[k];
-                    if (p.bias) x += cbias[k];
-                    if (p.emb) x += cemb[k];
-                    if (p.res) x += rr[k];
-                    v[k] = apply_act(x * p.out_scale, p.act);
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
-                if (p.out_mode == NLC_OUT_NHWC) {
-                    T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
-                    if (full) *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
-                    else {
+                STAMP(3);
+                load_frags(fa0, fb0, nast, bnext, std::integral_constant<int, ntap>{}, K0{});   // next step's first half
+                mma16(fa1, fb1);
 #pragma unroll
-                        for (int k = 0; k < PER; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
-                    }
-                } else {
-                    const int64_t rem = (int64_t)(y0 + py) * p.Win + x0 + px;
-#pragma unroll
-                    for (int k = 0; k < PER; ++k)
-                        if (n + k < p.Cout) reinterpret_cast<float*>(p.out)[((int64_t)tb * p.Cout + n + k) * HWo + rem] = v[k];
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
-            }
+                STAMP(5);
+                // retire weights kt+2; instructions younger than them may stay in flight:
+                // this step's weights kt+3 (NB) and a halo issued at this step (tap 0) or the previous one (tap 1)
+                if constexpr (tap <= 1) { if (more) dma_wait_h<NB + NA>(); else dma_wait_h<NB>(); }
+                else dma_wait_h<NB>();
+                STAMP(6);
+                __syncthreads();
+                STAMP(7);
+                STAMP_FLUSH();
+                bcur = bnext;
+                ++kt;
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+            hs ^= 1;
         }
+        epilogue(cur, nxt);                          // registers -> global, asynchronous stores; no LDS, no barrier
+        if (!has_next) break;
+        cur = nxt;
+        tl += gx;
     }
+    dma_wait_h<0>();          // the redundant tail fetches
 }
 
 template <typename T>
 int launch_halo(const KParams& p, hipStream_t stream) {
     static bool attr_set = false;
+    static int ncu = 0;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
         attr_set = true;
     }
-    const int grid = p.B * (p.Hin / PATCH) * (p.Win / PATCH) * p.NT;
+    const int nblk = p.B * (p.Hin / PATCH) * (p.Win / PATCH) * p.NT;
+    const int grid = nblk < ncu ? nblk : ncu;        // one persistent workgroup per CU (154 KiB of LDS each)
     hipLaunchKernelGGL((conv_halo_kernel<T>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(halo): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
@@ -332,6 +455,12 @@ int launch_halo(const KParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef HALO_STAMP
+extern "C" int nlc_debug_halo_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
 
 // 3x3 / stride 1 / pad 1 / no upsample, H and W multiples of 16, enough tiles to fill the chip.
 // NLC_CONV_HALO=0 disables, =1 forces (for eligible shapes) regardless of the tile count.
