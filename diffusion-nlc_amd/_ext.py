@@ -49,6 +49,8 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32),
         ("out", C.c_void_p),
         ("out_mode", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -86,6 +88,7 @@ SIGNATURES = {
     "nlc_last_error": (C.c_char_p, []),
     "nlc_conv_pack_dims": (C.c_int, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
+    "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "nlc_groupnorm_workspace_bytes": (C.c_int64, [_i, _i, _i, _i]),
     "nlc_groupnorm": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
 
     const int HWo = p.Hout * p.Wout;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
-    const int ncb = p.Cin_pad / KBE;
+    const int ncb_all = p.Cin_pad / KBE;
+    // split-K: blockIdx.y owns the channel blocks [cb0, cb1)
+    const int cb0 = (int)(((int64_t)ncb_all * blockIdx.y) / p.ksplit), cb1 = (int)(((int64_t)ncb_all * (blockIdx.y + 1)) / p.ksplit);
 
     // ---- per-row tap tables: input pixel index (within the whole tensor) and validity bit per tap
     int pix[4][TAPS];
@@ -159,20 +161,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
     //      next step into the other stage, compute this stage, wait for the own DMA, barrier.
     //      WAR safety: the stage being refilled was last read in the previous step, whose trailing
     //      barrier every wave has passed.
-    stage_step(0, 0, std::integral_constant<int, 0>{});
+    stage_step(0, cb0, std::integral_constant<int, 0>{});
     dma_wait_all();
     __syncthreads();
     int kt = 0;
-    for (int cb = 0; cb < ncb; ++cb) {
-        const bool last_cb = cb + 1 == ncb;
+    for (int cb = cb0; cb < cb1; ++cb) {
+        const bool last_cb = cb + 1 == cb1;
         auto body = [&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
             const int cur = kt & 1;
-            if (p.abl != 1) {
-                if constexpr (tap + 1 < TAPS) stage_step(cur ^ 1, cb, std::integral_constant<int, tap + 1>{});
-                else { if (!last_cb) stage_step(cur ^ 1, cb + 1, std::integral_constant<int, 0>{}); }
-            }
-            if (p.abl != 2) compute(cur);
+            if constexpr (tap + 1 < TAPS) stage_step(cur ^ 1, cb, std::integral_constant<int, tap + 1>{});
+            else { if (!last_cb) stage_step(cur ^ 1, cb + 1, std::integral_constant<int, 0>{}); }
+            compute(cur);
             dma_wait_all();
             __syncthreads();
             ++kt;
@@ -186,6 +186,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
         }
     }
 
+    // ---- split-K: raw f32 partial sums, [split][M][Cout]; bias / embedding / residual / activation are applied by
+    //      splitk_reduce_kernel, which adds the splits in a fixed order (deterministic)
+    if (p.ksplit > 1) {
+        float* part = p.partial + (int64_t)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + wm * 64 + i * 16 + fq * 4 + reg;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + fr;
+                    if (n < p.Cout) part[(int64_t)m * p.Cout + n] = acc[i][j][reg];
+                }
+            }
+        return;
+    }
     // ---- epilogue
     if (p.out_mode != NLC_OUT_NHWC) {          // NCHW f32 (last layer only): direct stores
 #pragma unroll
@@ -278,6 +296,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
     }
 }
 
+// out[m][n] = act((sum_s partial[s][m][n] + bias[n] + emb[b][n] + res[m][n]) * out_scale), 4 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;      // quad index
+    const int nq = p.Cout >> 2;
+    if (q >= (int64_t)p.M * nq) return;
+    const int64_t m = q / nq;
+    const int n = (int)(q - m * nq) * 4;
+    const int64_t off = m * p.Cout + n;
+    float4 v = *reinterpret_cast<const float4*>(p.partial + off);
+    for (int s = 1; s < p.ksplit; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(p.partial + (int64_t)s * p.M * p.Cout + off);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    float r[4] = {v.x, v.y, v.z, v.w};
+    const int HWo = p.Hout * p.Wout;
+    const int b = (int)(m / HWo);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x = r[k];
+        if (p.bias) x += p.bias[n + k];
+        if (p.emb) x += p.emb[(int64_t)b * p.emb_stride + n + k];
+        if (p.res) x += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + off + k);
+        r[k] = apply_act(x * p.out_scale, p.act);
+    }
+    if (p.out_mode == NLC_OUT_NHWC) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ElemTraits<T>::store(reinterpret_cast<T*>(p.out) + off + k, r[k]);
+    } else {
+        const int64_t rem = m - (int64_t)b * HWo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<float*>(p.out)[((int64_t)b * p.Cout + n + k) * HWo + rem] = r[k];
+    }
+}
+
 template <typename T, int TAPS>
 int launch_fast(const KParams& p, hipStream_t stream) {
     static bool attr_set = false;
@@ -285,13 +338,35 @@ int launch_fast(const KParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_fast_kernel<T, TAPS>), dim3(p.MT * p.NT), dim3(NTHREADS), LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_fast_kernel<T, TAPS>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), LDS_BYTES, stream, p);
+    if (p.ksplit > 1) {
+        const int64_t quads = (int64_t)p.M * (p.Cout >> 2);
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, stream, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(fast): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
 }
 
 }  // namespace
+
+// Split-K policy: bf16 only (the f32 parity path keeps one summation order), shapes with fewer output tiles than
+// 2 per CU and a long K; at least 2 channel blocks (18 / 2 k-steps) per split, at most 8 splits, aiming at >= 2
+// workgroups per CU (the 8x8 / 16x16 levels of ADM-256 at B = 16 have 64 / 256 tiles for 144-288 k-steps).
+int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
+    if (dtype != NLC_BF16 || (p.Cout & 3)) return 1;
+    const bool k3 = p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1;
+    const bool k1 = p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0;
+    if (p.stride != 1 || !(k3 || k1)) return 1;
+    const int tiles = p.MT * p.NT;
+    const int ncb = p.Cin_pad / Mma<bf16_raw>::KBE;
+    if (tiles >= 512) return 1;
+    int s = cdiv(512, tiles);
+    const int min_cb = k3 ? 2 : 8;                   // >= 18 (3x3) / 8 (1x1) k-steps per split
+    if (s > ncb / min_cb) s = ncb / min_cb;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : s;
+}
 
 // returns NLC_EUNSUPPORTED when the shape is not one the fast path handles (caller falls back)
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream) {

@@ -234,6 +234,20 @@ extern "C" int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult) {
     return NLC_OK;
 }
 
+extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype) {
+    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
+    KParams p{};
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Cout = d->Cout;
+    p.Cin_pad = d->Cin_pad; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.B = d->B;
+    p.ups = d->upsample2x ? 1 : 0;
+    const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
+    p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
+    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
+    if (!(p.Hout == HL && p.Wout == WL)) return 0;
+    const int ks = nlc_conv_fast_ksplit(p, dtype);
+    return ks > 1 ? (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(d != nullptr, "nlc_conv2d: null descriptor");
     NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv2d: bad dtype %d", dtype);
@@ -276,6 +290,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
     static const int abl = getenv("NLC_CONV_ABL") ? atoi(getenv("NLC_CONV_ABL")) : 0;
     p.abl = abl;
+    p.ksplit = 1; p.partial = nullptr;
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  NLC_CONV_GENERIC=1 forces the latter (A/B runs).
     static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
@@ -283,8 +298,15 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     if (!force_generic && p.Hout == HL && p.Wout == WL) {
         int rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
+        if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace
+            const int ks = nlc_conv_fast_ksplit(p, dtype);
+            if (ks > 1 && d->workspace_bytes >= (int64_t)ks * p.M * p.Cout * (int64_t)sizeof(float)) {
+                p.ksplit = ks; p.partial = (float*)d->workspace;
+            }
+        }
         rc = nlc_conv_fast_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
+        p.ksplit = 1; p.partial = nullptr;
     }
     if (dtype == NLC_BF16) return launch<bf16_raw>(p, (hipStream_t)stream);
     return launch<float>(p, (hipStream_t)stream);

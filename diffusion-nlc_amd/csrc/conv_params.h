@@ -21,10 +21,14 @@ struct KParams {
     const char* res; float out_scale; int act;
     char* out; int out_mode;
     int M, MT, NT;
+    int ksplit;         // conv_fast only: >1 = split the channel blocks over blockIdx.y, raw f32 partials to `partial`
+    float* partial;     // [ksplit][M][Cout] f32 (caller workspace); reduced + epilogue by splitk_reduce_kernel
     int abl;        // timing-only ablation (NLC_CONV_ABL): 1 = no staging in the k-loop, 2 = no MFMA work; results are wrong
 };
 
 // conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);
+// split-K policy for the shapes conv_fast takes (few output tiles, long K): number of splits, 1 = none
+int nlc_conv_fast_ksplit(const KParams& p, int dtype);
 // conv_halo.hip: 3x3 with the input halo resident in LDS; same return convention
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream);

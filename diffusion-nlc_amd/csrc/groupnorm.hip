@@ -256,22 +256,31 @@ __global__ __launch_bounds__(NT) void gn_stats_fast_kernel(const GNParams p) {
 
 // one workgroup per image: Chan-merge the per-block partials (f64, fixed order) -> (mean, rstd) per group,
 // written as two floats behind the partials of the image's block 0..nblk-1 region: stat[b][g] = {mean, rstd}
-__global__ void gn_finalize_kernel(const GNParams p, float* __restrict__ stat) {
+__global__ __launch_bounds__(NT) void gn_finalize_kernel(const GNParams p, float* __restrict__ stat) {
+    // 8 lanes per group walk the (up to 64) partials with stride 8 and combine by xor-shuffles in a fixed order
+    // (a single thread per group chained 2 x nblk dependent L2 loads: 13 us per launch, 2 ms per NLC step)
     const int b = blockIdx.x;
-    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+    const int sub = threadIdx.x & 7;
+    for (int g = threadIdx.x >> 3; g < p.G; g += NT / 8) {
         const double* w = p.ws + ((int64_t)b * p.nblk * p.G + g) * 3;
         double N = 0.0, sm = 0.0;
-        for (int k = 0; k < p.nblk; ++k) { const double* r = w + (int64_t)k * p.G * 3; N += r[0]; sm += r[0] * r[1]; }
+        for (int k = sub; k < p.nblk; k += 8) { const double* r = w + (int64_t)k * p.G * 3; N += r[0]; sm += r[0] * r[1]; }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { N += __shfl_xor(N, o, 64); sm += __shfl_xor(sm, o, 64); }
         const double mean = sm / N;
         double m2 = 0.0;
-        for (int k = 0; k < p.nblk; ++k) {
+        for (int k = sub; k < p.nblk; k += 8) {
             const double* r = w + (int64_t)k * p.G * 3;
             const double dm = r[1] - mean;
             m2 += r[2] + r[0] * dm * dm;
         }
-        const double var = m2 / N;
-        stat[((int64_t)b * p.G + g) * 2 + 0] = (float)mean;
-        stat[((int64_t)b * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+        if (sub == 0) {
+            const double var = m2 / N;
+            stat[((int64_t)b * p.G + g) * 2 + 0] = (float)mean;
+            stat[((int64_t)b * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
     }
 }
 
@@ -394,11 +403,11 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
         const int nblk_a = cdiv(HW, ppb);
         if (dtype == NLC_BF16) {
             hipLaunchKernelGGL(gn_stats_fast_kernel<bf16_raw>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-            hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, p, stat);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
             hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(nblk_a, B), dim3(NT), 0, st, p, stat, ppb);
         } else {
             hipLaunchKernelGGL(gn_stats_fast_kernel<float>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-            hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, p, stat);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
             hipLaunchKernelGGL(gn_apply_fast_kernel<float>, dim3(nblk_a, B), dim3(NT), 0, st, p, stat, ppb);
         }
     } else if (dtype == NLC_BF16) {

@@ -156,6 +156,11 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
                  out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC)
+    if dt == torch.bfloat16:                     # split-K scratch for the few-tile / long-K levels (a cheap host query)
+        need = lib.nlc_conv2d_workspace_bytes(C.byref(d), dtype_enum(dt))
+        if need > 0:
+            ws = _conv_workspace(x0.device, need)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     prof = CONV_PROFILE
     if prof is not None:
         # bench.py's roofline leg: HIP events on the launch stream around this one kernel
@@ -189,6 +194,17 @@ def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 
 
 _gn_ws = {}
+_conv_ws = {}
+
+
+def _conv_workspace(device, nbytes: int) -> torch.Tensor:
+    """Per (device, stream) scratch for nlc_conv2d's split-K partials; grows to the largest request."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    ws = _conv_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4 + 1, device=device, dtype=torch.float32)
+        _conv_ws[key] = ws
+    return ws
 
 
 def _gn_workspace(device, nbytes: int) -> torch.Tensor:

@@ -83,9 +83,14 @@ typedef struct nlc_conv_desc {
     int32_t act;         /* NLC_ACT_*                                            */
     void* out;           /* NLC_OUT_NHWC: compute dtype; NLC_OUT_NCHW_F32: float */
     int32_t out_mode;
+    void* workspace;     /* optional scratch (NULL = none): enables split-K on shapes with few output tiles and a long */
+    int64_t workspace_bytes; /* K (the 8x8 / 16x16 levels); size from nlc_conv2d_workspace_bytes, contents undefined   */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
+/* bytes of workspace with which nlc_conv2d would split K for this descriptor (0: it would not).  bf16 only - the
+ * f32 path keeps a single summation order.  Partial sums are f32 and are added in a fixed order. */
+int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype);
 
 /* First-layer convolution for tiny Cin (<=4): reads the sampler state in the reference's
  * own layout (NCHW f32), applies the per-sample input scale c_in[b] (convert_coordinate,

@@ -60,6 +60,10 @@ CONV_CASES = [
     dict(B=1, Cin=32, H=32, W=16, Cout=6, k=3, act="silu", nchw=True),
     dict(B=3, Cin=192, H=16, W=16, Cout=128, k=3, act="gelu"),
     dict(B=1, Cin=128, H=48, W=32, Cout=256, k=3, bias=False),
+    # few output tiles + long K: split-K in bf16 (2 / 4 / 2 splits), partials reduced in a second kernel
+    dict(B=2, Cin=256, H=8, W=8, Cout=128, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
+    dict(B=1, Cin=512, H=8, W=8, Cout=72, k=3, act="silu", nchw=True),
+    dict(B=2, Cin=1024, H=4, W=4, Cout=256, k=1, res=True),
 ]
 
 
