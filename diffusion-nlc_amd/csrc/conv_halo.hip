@@ -388,8 +388,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     }
                 };
                 STAMP(0);
-                issue_dma();
-                STAMP(1);
                 // Each half: 8 fragment reads for a LATER cluster + 16 MFMAs.  The sched_group_barrier pattern makes the
                 // backend interleave them as [1 ds_read, 2 MFMA] x 8 instead of "all reads, then all MFMAs": an MFMA holds
                 // the SIMD's issue port for 8 of its 16 cycles, so a read slipped into each gap costs ~nothing and a wave
@@ -403,6 +401,11 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
                 STAMP(3);
+                // DMA issue (~90 cycles per instruction for the issuing wave) sits BETWEEN the two MFMA clusters: a step
+                // starts with matrix work that is already in registers, and the first-dispatched waves 0-3 (which run
+                // ahead of their SIMD partners by ~150 cycles after every barrier) issue while waves 4-7 still compute.
+                issue_dma();
+                STAMP(1);
                 load_frags(fa0, fb0, nast, bnext, std::integral_constant<int, ntap>{}, K0{});   // next step's first half
                 mma16(fa1, fb1);
 #pragma unroll
