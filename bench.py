@@ -184,7 +184,7 @@ def main():
             n = sum(1 for _, _, _, d, _s in prof if d == dtype)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             peak = PEAK_BF16_DENSE_TFLOPS if dtype == torch.bfloat16 else 157.3
-            line["roofline"] = {"bound": "mfma", "kernel": f"nlc_conv2d: conv_fast_kernel<{args.dtype},9|1> (+ conv_igemm_kernel for strided shapes)",
+            line["roofline"] = {"bound": "mfma", "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3 on >= 32x32 maps, 75 % of its time) + conv_fast_kernel<{args.dtype},9|1> (+ splitk_reduce) + conv_igemm_kernel (strided)",
                                 "achieved": ach, "peak": peak,
                                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
                                 "avg_launch_us": 1e3 * tot_ms / max(n, 1), "avg_launch_gflop": tot_fl / max(n, 1) / 1e9,
