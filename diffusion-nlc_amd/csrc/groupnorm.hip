@@ -293,11 +293,29 @@ __global__ __launch_bounds__(NT) void gn_apply_fast_kernel(const GNParams p, con
     const int tx = tid % p.tpp, pl = tid / p.tpp;
     const int c0 = tx * PER;
     float ca[PER], cb[PER];
+    float mean = 0.f, rstd = 0.f;
+    int gprev = -1;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int c = c0 + j;
         const int g = c / p.gs;
-        const float mean = stat[((int64_t)b * p.G + g) * 2], rstd = stat[((int64_t)b * p.G + g) * 2 + 1];
+        if (stat) { mean = stat[((int64_t)b * p.G + g) * 2]; rstd = stat[((int64_t)b * p.G + g) * 2 + 1]; }
+        else if (g != gprev) {
+            // few partials (small maps): every thread folds them itself, same f64 Chan merge and order as gn_finalize
+            const double* w = p.ws + ((int64_t)b * p.nblk * p.G + g) * 3;
+            double N = 0.0, sm = 0.0;
+            for (int k = 0; k < p.nblk; ++k) { const double* r = w + (int64_t)k * p.G * 3; N += r[0]; sm += r[0] * r[1]; }
+            const double mu = sm / N;
+            double m2 = 0.0;
+            for (int k = 0; k < p.nblk; ++k) {
+                const double* r = w + (int64_t)k * p.G * 3;
+                const double dm = r[1] - mu;
+                m2 += r[2] + r[0] * dm * dm;
+            }
+            mean = (float)mu;
+            rstd = (float)(1.0 / sqrt(m2 / N + (double)p.eps));
+            gprev = g;
+        }
         float a = rstd * (p.gamma ? p.gamma[c] : 1.f);
         float bb = (p.beta ? p.beta[c] : 0.f) - mean * a;
         if (p.scale) {
@@ -350,7 +368,7 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
     p.nslot = cdiv(p.nch, p.tpp);
     p.ps = NT / p.tpp; if (p.ps < 1) p.ps = 1;
     int64_t bytes = (int64_t)HW * p.C * es;
-    int nblk = cdiv(bytes, 65536);
+    int nblk = cdiv(bytes, 16384);                   // >= 16 KiB per stats block: small maps are latency-, not bandwidth-bound
     if (nblk < 1) nblk = 1;
     if (nblk > MAX_NBLK) nblk = MAX_NBLK;
     if (nblk > HW) nblk = HW;
@@ -401,13 +419,15 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
         int ppb = p.ps * UNR * 4;
         while ((int64_t)cdiv(HW, ppb) * B > 8192) ppb *= 2;
         const int nblk_a = cdiv(HW, ppb);
+        const bool inline_fin = p.nblk <= 8;         // small maps: no finalize launch, the apply threads fold the partials
+        if (inline_fin) stat = nullptr;
         if (dtype == NLC_BF16) {
             hipLaunchKernelGGL(gn_stats_fast_kernel<bf16_raw>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-            hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
+            if (!inline_fin) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
             hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(nblk_a, B), dim3(NT), 0, st, p, stat, ppb);
         } else {
             hipLaunchKernelGGL(gn_stats_fast_kernel<float>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-            hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
+            if (!inline_fin) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
             hipLaunchKernelGGL(gn_apply_fast_kernel<float>, dim3(nblk_a, B), dim3(NT), 0, st, p, stat, ppb);
         }
     } else if (dtype == NLC_BF16) {
