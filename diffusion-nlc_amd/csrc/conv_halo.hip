@@ -28,7 +28,7 @@
 
 namespace {
 
-__device__ uint4 g_zero_page_h[8];
+__device__ uint4 g_zero_page_h[1024];            // 16 KiB of zeros: out-of-image halo rows read it at offset cb * 128 B (cb < 128)
 
 constexpr int HT = 512;                         // threads
 constexpr int PATCH = 16;                       // output patch edge
@@ -92,9 +92,13 @@ struct TileH { int tb, y0, x0, n0; };
 // ---- diagnostic build only (-DHALO_STAMP): s_memtime stamps around the phases of ONE k-step (tile 1, cb 1, tap 4) of
 //      workgroup 0, per wave; read back with nlc_debug_halo_stamps.  No stamp executes in the normal build.
 #ifdef HALO_STAMP
+#ifndef HALO_STAMP_TAP
+#define HALO_STAMP_TAP 4
+#endif
+__device__ unsigned long long g_halo_clock[4];     // {s_memtime, s_memrealtime} at loop start / end of workgroup 0, wave 0
 __device__ unsigned long long g_halo_stamps[8][8];
-#define STAMP(i) do { if (stamp_on && tap == 4) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define STAMP_FLUSH() do { if (stamp_on && tap == 4 && lane == 0) { for (int q_ = 0; q_ < 8; ++q_) g_halo_stamps[wave][q_] = st[q_]; } } while (0)
+#define STAMP(i) do { if (stamp_on && tap == HALO_STAMP_TAP) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define STAMP_FLUSH() do { if (stamp_on && tap == HALO_STAMP_TAP && lane == 0) { for (int q_ = 0; q_ < 8; ++q_) g_halo_stamps[wave][q_] = st[q_]; } } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #define STAMP_FLUSH() do {} while (0)
@@ -142,37 +146,39 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     const int nk = ncb * 9;
 
     // ---- this lane's (up to) 6 halo rows: DMA instruction q = wave + 8 j covers LDS rows 8q .. 8q+7; q >= 41 is padding.
-    //      (hy, hx) never change; the source pixel is recomputed per tile.  Source-side swizzle: R & 7 == lrow.
-    int hpix[NA];
-    unsigned hvalid = 0;
+    //      Per tile and per input segment (x0 | x1 of a concatenated input) the lane keeps the 64-bit source address of
+    //      its chunk in channel block 0 of that segment - or of the zero page for out-of-image rows - so that issuing
+    //      the halo of channel block cb is ONE uniform 64-bit add per instruction (the per-instruction pixel * C
+    //      multiply, source select and zero-page select used to cost ~175 issue cycles per DMA, 1000+ per halo).
+    //      Source-side swizzle: R & 7 == lrow.
+    const char* haddr[NA];
     const int hchunk = lslot ^ lrow;
-    auto halo_addr = [&](const TileH& t) {           // once per tile: (hy, hx) of this lane's rows are recomputed, not kept
-        hvalid = 0;
+    const int cbs1 = p.C0 / KBE;                     // first channel block of the second segment (dispatch: C0 % KBE == 0)
+    const char* zero = reinterpret_cast<const char*>(g_zero_page_h);
+    auto halo_addr = [&](const TileH& t, int seg) {
+        const char* src = seg ? p.x1 : p.x0;
+        const int C = seg ? p.C1 : p.C0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int R = (wave + 8 * j) * 8 + lrow;  // DMA instruction q = wave + 8 j covers LDS rows 8q .. 8q+7; q >= 41 is padding
+            const int R = (wave + 8 * j) * 8 + lrow;
             const int hy = R / HALO, hx = R - hy * HALO;
             const int iy = t.y0 + hy - 1, ix = t.x0 + hx - 1;
             const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-            hpix[j] = ok ? (t.tb * p.Hin + iy) * p.Win + ix : 0;
-            hvalid |= (ok ? 1u : 0u) << j;
+            const int64_t pixel = ((int64_t)t.tb * p.Hin + iy) * p.Win + ix;
+            haddr[j] = ok ? src + (pixel * C + hchunk * PER) * ES : zero;
         }
     };
     const int64_t wrow = (int64_t)9 * p.Cin_pad * ES;
-    const char* zero = reinterpret_cast<const char*>(g_zero_page_h);
 
-    auto issue_A = [&](int cb, int astage) {
+    // halo instructions [J0, J0 + N) of channel block cb (of the segment haddr was set up for)
+    auto issue_A = [&](int cb, int astage, auto j0_c, auto n_c) {
+        constexpr int J0 = decltype(j0_c)::value, N = decltype(n_c)::value;
         const unsigned base = lds0 + astage * A_STAGE + wave * 8 * KB_BYTES;
-        const int cch = cb * KBE + hchunk * PER;
-        const char* src; int C, ch;
-        if (cch < p.C0) { src = p.x0; C = p.C0; ch = cch; } else { src = p.x1; C = p.C1; ch = cch - p.C0; }
-        const bool chok = cch < p.Ctot;
+        const int64_t off = (int64_t)(cb >= cbs1 && p.C1 > 0 ? cb - cbs1 : cb) * (KBE * ES);     // wave-uniform
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const bool ok = ((hvalid >> j) & 1u) && chok;
-            const char* ptr = ok ? src + ((int64_t)hpix[j] * C + ch) * ES : zero;
+        for (int j = J0; j < J0 + N; ++j) {
             const bool real = (wave + 8 * j) < A_INSTR;                       // wave-uniform
-            glds16h(ptr, real ? base + j * 64 * KB_BYTES : ldsScratch);      // every wave issues exactly NA instructions
+            glds16h(haddr[j] + off, real ? base + j * 64 * KB_BYTES : ldsScratch);
         }
     };
     unsigned woff[NB];                               // per-lane byte offset of this lane's weight row + chunk (constant)
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             int64_t mrow[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) mrow[i] = ((int64_t)t.tb * p.Hin + t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
-            constexpr bool HOIST = NCH <= 2;         // bf16: all 8 residual chunks in flight at once (f32 would spill)
+            constexpr bool HOIST = false;            // (hoisting all 8 residual chunks ahead of the stores costs 32 VGPRs: spills)
             uint4 rres[HOIST ? 4 : 1][NCH];
             if (HOIST && p.res && full) {
 #pragma unroll
@@ -340,8 +346,8 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         load_cadd(cur, c0);
         init_acc(c0);
     }
-    halo_addr(cur);
-    issue_A(0, 0);
+    halo_addr(cur, 0);
+    issue_A(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
     issue_B(cur.n0, 0, 0);
     issue_B(cur.n0, min(1, nk - 1), 1);
     issue_B(cur.n0, min(2, nk - 1), 2);
@@ -354,6 +360,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // (Tried and measured slower on this kernel, 1.18 vs 1.12 ms on 256->256 @256^2: running SIMD partner waves in
     //  complementary orders by giving waves 0-3 / 4-7 their barrier at different points of one instruction stream.)
     constexpr int wdist = 3;                         // weight tiles run 3 k-steps ahead
+#ifdef HALO_STAMP
+    if (blockIdx.x == 0 && tid == 0) { g_halo_clock[0] = __builtin_amdgcn_s_memtime(); g_halo_clock[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     int bcur = 0, hs = 0;                            // weight stage / halo stage of the current k-step (run across tiles)
     for (;;) {
         const bool has_next = tl + gx < chunk_len;
@@ -380,10 +389,14 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     const int k3 = kt + wdist;
                     const bool wrap = k3 >= nk;
                     issue_B(wrap ? nxt.n0 : cur.n0, wrap ? (has_next ? k3 - nk : nk - 1) : k3, (bcur + wdist) & 3);
-                    if constexpr (tap == 0) {
+                    // the next halo goes out two instructions per step over taps 0-2, AFTER the step's weights (needed first)
+                    if constexpr (tap <= 2) {
                         if (more) {
-                            if (last_cb) halo_addr(nxt);
-                            issue_A(last_cb ? 0 : cb + 1, hs ^ 1);  // AFTER the weights: they are needed first
+                            if constexpr (tap == 0) {
+                                if (last_cb) halo_addr(nxt, 0);
+                                else if (p.C1 > 0 && cb + 1 == cbs1) halo_addr(cur, 1);
+                            }
+                            issue_A(last_cb ? 0 : cb + 1, hs ^ 1, std::integral_constant<int, 2 * tap>{}, std::integral_constant<int, 2>{});
                         }
                     }
                 };
@@ -415,8 +428,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 }
                 STAMP(5);
                 // retire weights kt+2; instructions younger than them may stay in flight:
-                // this step's weights kt+3 (NB) and a halo issued at this step (tap 0) or the previous one (tap 1)
-                if constexpr (tap <= 1) { if (more) dma_wait_h<NB + NA>(); else dma_wait_h<NB>(); }
+                // this step's weights kt+3 (NB) and the halo instructions issued at this step or the previous one
+                // (issue order per step: weights, then 2 halo instructions at taps 0-2)
+                if constexpr (tap == 0 || tap == 3) { if (more) dma_wait_h<NB + 2>(); else dma_wait_h<NB>(); }
+                else if constexpr (tap == 1 || tap == 2) { if (more) dma_wait_h<NB + 4>(); else dma_wait_h<NB>(); }
                 else dma_wait_h<NB>();
                 STAMP(6);
                 __syncthreads();
@@ -435,6 +450,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         cur = nxt;
         tl += gx;
     }
+#ifdef HALO_STAMP
+    if (blockIdx.x == 0 && tid == 0) { g_halo_clock[2] = __builtin_amdgcn_s_memtime(); g_halo_clock[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     dma_wait_h<0>();          // the redundant tail fetches
 }
 
@@ -461,7 +479,9 @@ int launch_halo(const KParams& p, hipStream_t stream) {
 
 #ifdef HALO_STAMP
 extern "C" int nlc_debug_halo_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamps), sizeof(unsigned long long) * 64);
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamps), sizeof(unsigned long long) * 64);
+    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(g_halo_clock), sizeof(unsigned long long) * 4);
+    return rc;
 }
 #endif
 
@@ -472,6 +492,10 @@ int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (force && force[0] == '0') return NLC_EUNSUPPORTED;
     if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1 && !p.ups)) return NLC_EUNSUPPORTED;
     if (p.Hin % PATCH || p.Win % PATCH || p.Hout != p.Hin || p.Wout != p.Win) return NLC_EUNSUPPORTED;
+    {   // whole 128-byte channel blocks per input segment (the halo DMA adds one uniform offset per block); <= 128 blocks
+        const int kbe = dtype == NLC_BF16 ? MmaH<bf16_raw>::KBE : MmaH<float>::KBE;
+        if (p.C0 % kbe || p.C1 % kbe || p.Cin_pad / kbe > 128) return NLC_EUNSUPPORTED;
+    }
     if ((int64_t)p.B * p.Hin * p.Win >= (1ll << 31)) return NLC_EUNSUPPORTED;
     const int blocks = p.B * (p.Hin / PATCH) * (p.Win / PATCH) * p.NT;
     if (!(force && force[0] == '1') && blocks < 256) return NLC_EUNSUPPORTED;

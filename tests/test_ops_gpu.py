@@ -55,11 +55,16 @@ CONV_CASES = [
     dict(B=2, Cin=64, H=8, W=8, Cout=16, k=3, act="gelu", nchw=True),
     dict(B=1, Cin=256, H=32, W=32, Cout=256, k=3),                   # multi-tile M and N
     dict(B=2, Cin=64, H=2, W=2, Cout=64, k=3),                       # 2x2 image (sigma net tail)
-    # shapes eligible for the LDS-halo kernel (H, W multiples of 16; forced with NLC_CONV_HALO=1)
+    # shapes eligible for the LDS-halo kernel (H, W multiples of 16, whole channel blocks; forced by tests/conftest.py)
     dict(B=2, Cin=96, H=16, W=32, Cout=200, k=3, split=40, emb=True, res=True, scale=math.sqrt(0.5)),
     dict(B=1, Cin=32, H=32, W=16, Cout=6, k=3, act="silu", nchw=True),
     dict(B=3, Cin=192, H=16, W=16, Cout=128, k=3, act="gelu"),
     dict(B=1, Cin=128, H=48, W=32, Cout=256, k=3, bias=False),
+    dict(B=2, Cin=192, H=16, W=32, Cout=200, k=3, split=64, emb=True, res=True, scale=math.sqrt(0.5)),   # concat at a block edge
+    dict(B=2, Cin=64, H=32, W=32, Cout=6, k=3, act="silu", nchw=True),
+    # > 256 tiles: every persistent workgroup walks 2 tiles (cross-tile DMA streams, accumulator re-init, both N-tiles)
+    dict(B=1, Cin=64, H=256, W=256, Cout=256, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
+    dict(B=2, Cin=128, H=256, W=128, Cout=256, k=3, split=64, act="silu"),
     # few output tiles + long K: split-K in bf16 (2 / 4 / 2 splits), partials reduced in a second kernel
     dict(B=2, Cin=256, H=8, W=8, Cout=128, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
     dict(B=1, Cin=512, H=8, W=8, Cout=72, k=3, act="silu", nchw=True),

@@ -15,16 +15,24 @@ dev = torch.device("cuda:0")
 x = torch.randn(16, H, H, cin, device=dev).to(torch.bfloat16)
 w = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
 pw = ops.pack_conv(w, torch.zeros(cout), torch.bfloat16, dev)
-for _ in range(5):
-    ops.conv2d(x, pw)
+import time
+t_end = time.time() + 2.5                       # >= 2 s of back-to-back launches so the clock settles under load
+while time.time() < t_end:
+    for _ in range(20):
+        ops.conv2d(x, pw)
+    torch.cuda.synchronize()
 torch.cuda.synchronize()
 lib = _ext.load()
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 68)()
 lib.nlc_debug_halo_stamps.argtypes = [ctypes.c_void_p]
 rc = lib.nlc_debug_halo_stamps(buf)
 st = [[buf[w_ * 8 + q] for q in range(8)] for w_ in range(8)]
 t0 = min(s[0] for s in st)
 names = ["start", "dma issued", "reads1 issued", "mfma1 issued", "reads2 issued", "mfma2 issued", "vmcnt done", "barrier done"]
+clk = [buf[64 + i] for i in range(4)]
+if clk[3] > clk[1]:
+    print(f"in-kernel clock of workgroup 0 over its whole tile loop: {(clk[2] - clk[0]) / (clk[3] - clk[1]) * 100:.0f} MHz "
+          f"(ds_memtime / ds_memrealtime x 100 MHz; loop = {(clk[3] - clk[1]) / 100:.1f} us)")
 print("rc", rc, " (s_memtime ticks relative to the earliest wave's step start)")
 print("wave " + " ".join(f"{n:>14s}" for n in names))
 for w_ in range(8):
