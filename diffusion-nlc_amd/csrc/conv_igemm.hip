@@ -288,8 +288,6 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act;
     p.out = (char*)d->out; p.out_mode = d->out_mode;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
-    static const int abl = getenv("NLC_CONV_ABL") ? atoi(getenv("NLC_CONV_ABL")) : 0;
-    p.abl = abl;
     p.ksplit = 1; p.partial = nullptr;
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  NLC_CONV_GENERIC=1 forces the latter (A/B runs).

@@ -23,7 +23,6 @@ struct KParams {
     int M, MT, NT;
     int ksplit;         // conv_fast only: >1 = split the channel blocks over blockIdx.y, raw f32 partials to `partial`
     float* partial;     // [ksplit][M][Cout] f32 (caller workspace); reduced + epilogue by splitk_reduce_kernel
-    int abl;        // timing-only ablation (NLC_CONV_ABL): 1 = no staging in the k-loop, 2 = no MFMA work; results are wrong
 };
 
 // conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)

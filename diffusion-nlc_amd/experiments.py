@@ -293,6 +293,15 @@ class ExperimentDiffusion:
         best_val, best_x0 = 10000, xt
         x0 = xt
         st["nan"].zero_()
+        # The reference reads torch.isnan(xt).any() on the host after every step (:389).  Without logging / constraint
+        # losses nothing else needs the host, so that read is taken one step late: step i's (sticky) flag is copied to
+        # pinned memory behind step i, and looked at after step i+1 has been queued - the GPU never drains.  A NaN at
+        # step i then discards the already-queued step i+1 and returns what the reference's break returns.
+        lazy_nan = self.check_nan and not return_log and constrain_loss is None
+        if lazy_nan:
+            flag_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            flag_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            x0_before = x0
         for ind, (t, t_prev) in enumerate(pairwise(ts_host.tolist())):
             if ind == S.num_inference_steps - 1 and new_eta is not None:
                 S.eta = new_eta
@@ -319,7 +328,16 @@ class ExperimentDiffusion:
                 eps_list.append(eps_used.cpu())
                 x0_prec_list.append(x0_hat.cpu())
                 x0_postc_list.append(x0.cpu())
-            if self.check_nan and int(st["nan"].item()) != 0:       # torch.isnan(xt).any() -> break (:389)
+            if lazy_nan:
+                flag_host[ind & 1:(ind & 1) + 1].copy_(st["nan"], non_blocking=True)
+                flag_ev[ind & 1].record()
+                if ind > 0:
+                    flag_ev[(ind - 1) & 1].synchronize()
+                    if int(flag_host[(ind - 1) & 1]) != 0:        # NaN at step ind-1: the reference stopped there
+                        x0 = best_x0 = x0_before
+                        break
+                x0_before = x0
+            elif self.check_nan and int(st["nan"].item()) != 0:       # torch.isnan(xt).any() -> break (:389)
                 break
         S.eta = eta0
         out = (best_x0 if return_best else x0).cpu()

@@ -79,6 +79,28 @@ def test_loop_without_logging_is_identical():
     assert torch.equal(x1, x2) and logs[1] == []
 
 
+def test_nan_break_is_the_same_eager_and_deferred():
+    """A NaN state ends the loop (src/experiments.py:389).  With logging the flag is read every step; without, one step
+    late and without draining the queue - both must stop at the same step and return the same tensor."""
+    from diffusion_nlc_amd.experiments import ImageExperiment
+    from diffusion_nlc_amd.schedulers import get_sampler
+    eps, sig = _models("simple_tiny", torch.float32)
+    s = get_sampler("ddim", 1000, 6, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    s.to("cuda:0")
+    exp = ImageExperiment(eps, s, batch_size=2, data_shape=(3, 32, 32), seed=3, device="cuda:0")
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 54.63)
+    exp.set_clip_fn("none")
+    xT = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(5)) * 100
+    xT[1, 2, 7, 9] = float("nan")
+    kw = dict(shape=(2, 3, 32, 32), xT=xT, style="base", norm_eps=False, refine_prior_sigma=False, chunk_size=1)
+    xa, logs = exp.denoise_loop(return_log=True, **kw)
+    xb, _ = exp.denoise_loop(return_log=False, **kw)
+    assert len(logs[1]) == 1                                   # stopped after the first step
+    assert torch.isnan(xa).any() and torch.equal(torch.isnan(xa), torch.isnan(xb))
+    assert torch.equal(torch.nan_to_num(xa), torch.nan_to_num(xb))
+
+
 @pytest.mark.parametrize("name", ["loop_edm_pred", "loop_edm_base", "loop_edm_euler", "loop_edm_cos", "loop_edm_p3"])
 def test_f32_edm_sampler_matches_reference(name):
     """EDM / Heun + NLC (float64 state, float32 network) vs the reference's own edm_sampler output."""

@@ -2,7 +2,6 @@
 """Micro-benchmark of nlc_conv2d on the ADM-256 hot shapes (B=16), HIP events on the launch stream.
 
     python tools/conv_bench.py [--reps 20]
-    NLC_CONV_ABL=1|2 python tools/conv_bench.py      # timing-only ablations (no staging / no MFMA)
 """
 import argparse
 import math
