@@ -51,6 +51,8 @@ class ConvDesc(C.Structure):
         ("out_mode", C.c_int32),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64),
+        ("stats_out", C.c_void_p),
+        ("stats_bytes", C.c_int64),
     ]
 
 
@@ -89,9 +91,11 @@ SIGNATURES = {
     "nlc_conv_pack_dims": (C.c_int, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
+    "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "nlc_groupnorm_workspace_bytes": (C.c_int64, [_i, _i, _i, _i]),
     "nlc_groupnorm": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "nlc_groupnorm_prestats": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "nlc_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nlc_avgpool2x2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nlc_upsample2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         float cnext[16];
         load_cadd(nx, cnext);                        // in flight while this tile is stored
         const int n = t.n0 + wn * 64 + fq * 16;
+        float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};        // this lane's two 8-channel chunks over its 4 pixels
         if (n < p.Cout) {
             const bool full = vec_ok && (n + 16 <= p.Cout);
             constexpr int NCH = 16 / PER;
@@ -324,7 +325,21 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
                     if (full) {
 #pragma unroll
-                        for (int c = 0; c < NCH; ++c) *reinterpret_cast<uint4*>(op + c * PER) = f32_to_chunk<T>(v + c * PER);
+                        for (int c = 0; c < NCH; ++c) {
+                            const uint4 pk = f32_to_chunk<T>(v + c * PER);
+                            *reinterpret_cast<uint4*>(op + c * PER) = pk;
+                            if constexpr (sizeof(T) == 2) {
+                                if (p.stats) {           // GroupNorm statistics of what was just stored (the rounded values)
+                                    const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const float lo = __uint_as_float(wds[q] << 16), hi = __uint_as_float(wds[q] & 0xffff0000u);
+                                        gsum[c] += lo; gsum[c] += hi;
+                                        gsq[c] = fmaf(lo, lo, gsq[c]); gsq[c] = fmaf(hi, hi, gsq[c]);
+                                    }
+                                }
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
@@ -334,6 +349,22 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                         if (n + k < p.Cout) reinterpret_cast<float*>(p.out)[((int64_t)t.tb * p.Cout + n + k) * HWo + rem] = v[k];
+                }
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (p.stats && n + 16 <= p.Cout) {
+                // reduce over the 16 pixel lanes (fr) of this quarter-wave in a fixed order, then one 16-byte store per
+                // (patch, M-wave, 16-channel slice): stats[b][partial][chunk][{sum, sumsq}]
+                float r4[4] = {gsum[0], gsq[0], gsum[1], gsq[1]};
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r4[q] += __shfl_xor(r4[q], o, 64);
+                if (fr == 0) {
+                    const int part = ((t.y0 / PATCH) * tiles_x + t.x0 / PATCH) * 4 + wm;
+                    float* dst = p.stats + (((int64_t)t.tb * p.stats_P + part) * (p.Cout >> 3) + (n >> 3)) * 2;
+                    *reinterpret_cast<float4*>(dst) = float4{r4[0], r4[1], r4[2], r4[3]};
                 }
             }
         }
@@ -485,19 +516,30 @@ extern "C" int nlc_debug_halo_stamps(unsigned long long* out) {
 }
 #endif
 
+static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
+    static const char* force = getenv("NLC_CONV_HALO");
+    const bool forced = force && force[0] == '1';
+    if (forced_out) *forced_out = forced;
+    if (force && force[0] == '0') return false;
+    if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1 && !p.ups)) return false;
+    if (p.Hin % PATCH || p.Win % PATCH || p.Hout != p.Hin || p.Wout != p.Win) return false;
+    const int kbe = dtype == NLC_BF16 ? MmaH<bf16_raw>::KBE : MmaH<float>::KBE;
+    if (p.C0 % kbe || p.C1 % kbe || p.Cin_pad / kbe > 128) return false;
+    if ((int64_t)p.B * p.Hin * p.Win >= (1ll << 31)) return false;
+    const int blocks = p.B * (p.Hin / PATCH) * (p.Win / PATCH) * p.NT;
+    return forced || blocks >= 256;
+}
+
+// GroupNorm statistics ride along when the halo kernel runs in bf16 with NHWC output and whole 128-channel N-tiles
+int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
+    if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
+    if (!halo_eligible(p, dtype, nullptr)) return 0;
+    return (p.Hin / PATCH) * (p.Win / PATCH) * 4;
+}
+
 // 3x3 / stride 1 / pad 1 / no upsample, H and W multiples of 16, enough tiles to fill the chip.
 // NLC_CONV_HALO=0 disables, =1 forces (for eligible shapes) regardless of the tile count.
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
-    static const char* force = getenv("NLC_CONV_HALO");
-    if (force && force[0] == '0') return NLC_EUNSUPPORTED;
-    if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1 && !p.ups)) return NLC_EUNSUPPORTED;
-    if (p.Hin % PATCH || p.Win % PATCH || p.Hout != p.Hin || p.Wout != p.Win) return NLC_EUNSUPPORTED;
-    {   // whole 128-byte channel blocks per input segment (the halo DMA adds one uniform offset per block); <= 128 blocks
-        const int kbe = dtype == NLC_BF16 ? MmaH<bf16_raw>::KBE : MmaH<float>::KBE;
-        if (p.C0 % kbe || p.C1 % kbe || p.Cin_pad / kbe > 128) return NLC_EUNSUPPORTED;
-    }
-    if ((int64_t)p.B * p.Hin * p.Win >= (1ll << 31)) return NLC_EUNSUPPORTED;
-    const int blocks = p.B * (p.Hin / PATCH) * (p.Win / PATCH) * p.NT;
-    if (!(force && force[0] == '1') && blocks < 256) return NLC_EUNSUPPORTED;
+    if (!halo_eligible(p, dtype, nullptr)) return NLC_EUNSUPPORTED;
     return dtype == NLC_BF16 ? launch_halo<bf16_raw>(p, stream) : launch_halo<float>(p, stream);
 }

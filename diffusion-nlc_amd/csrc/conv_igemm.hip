@@ -248,6 +248,24 @@ extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype)
     return ks > 1 ? (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) : 0;
 }
 
+static void geometry_only(const nlc_conv_desc* d, KParams& p) {
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Cout = d->Cout;
+    p.Cin_pad = d->Cin_pad; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.B = d->B;
+    p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
+    p.ups = d->upsample2x ? 1 : 0; p.out_mode = d->out_mode;
+    const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
+    p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
+}
+
+extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
+    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
+    static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
+    if (force_generic) return 0;
+    KParams p{};
+    geometry_only(d, p);
+    return nlc_conv_halo_stats_partials(p, dtype);
+}
+
 extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(d != nullptr, "nlc_conv2d: null descriptor");
     NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv2d: bad dtype %d", dtype);
@@ -289,13 +307,21 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.out = (char*)d->out; p.out_mode = d->out_mode;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
     p.ksplit = 1; p.partial = nullptr;
+    p.stats = nullptr; p.stats_P = 0;
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  NLC_CONV_GENERIC=1 forces the latter (A/B runs).
     static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     if (!force_generic && p.Hout == HL && p.Wout == WL) {
+        if (d->stats_out) {
+            const int P = nlc_conv_halo_stats_partials(p, dtype);
+            NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
+            NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / 8) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
+            p.stats = (float*)d->stats_out; p.stats_P = P;
+        }
         int rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
+        p.stats = nullptr; p.stats_P = 0;
         if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace
             const int ks = nlc_conv_fast_ksplit(p, dtype);
             if (ks > 1 && d->workspace_bytes >= (int64_t)ks * p.M * p.Cout * (int64_t)sizeof(float)) {

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const GNParams p) {
 }
 
 // ---- fast path: nslot == 1 ---------------------------------------------------------------------------------
-constexpr int UNR = 4;
+constexpr int UNR = 8;
 
 template <typename T>
 __global__ __launch_bounds__(NT) void gn_stats_fast_kernel(const GNParams p) {
@@ -281,6 +281,44 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const GNParams p, float
             stat[((int64_t)b * p.G + g) * 2 + 0] = (float)mean;
             stat[((int64_t)b * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
         }
+    }
+}
+
+// Statistics that rode along in the producing convolutions' epilogues (nlc_conv_desc.stats_out): per source a float
+// array [B][P][C_src/8][2] of (sum, sum of squares) per 8-channel chunk and partial.  One workgroup per (group, image)
+// adds the group's chunks over all partials in f64 in a fixed order (thread t takes partials t, t+256, ...; tree over
+// the threads) -> (mean, rstd) in the same stat[b][g] table gn_finalize writes.
+__global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __restrict__ s0, int P0, int C0,
+                                                              const float* __restrict__ s1, int P1, int C1,
+                                                              int gs, int G, int HW, float eps, float* __restrict__ stat) {
+    __shared__ double red[2][NT];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int q0 = g * gs / 8, q1 = (g + 1) * gs / 8;           // chunk range of this group over cat(x0, x1)
+    const int nq0 = C0 / 8, nq1 = C1 / 8;
+    double a = 0.0, c = 0.0;
+    for (int q = q0; q < q1; ++q) {
+        const bool second = q >= nq0;
+        const float* src = second ? s1 : s0;
+        const int P = second ? P1 : P0, nq = second ? nq1 : nq0, qq = second ? q - nq0 : q;
+        const float* base = src + ((int64_t)b * P * nq + qq) * 2;
+        for (int pp = tid; pp < P; pp += NT) {
+            const float2 v = *reinterpret_cast<const float2*>(base + (int64_t)pp * nq * 2);
+            a += (double)v.x; c += (double)v.y;
+        }
+    }
+    red[0][tid] = a; red[1][tid] = c;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double N = (double)HW * gs;
+        const double mean = red[0][0] / N;
+        double var = red[1][0] / N - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[((int64_t)b * G + g) * 2 + 0] = (float)mean;
+        stat[((int64_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -438,5 +476,35 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk2, B), dim3(NT), lds_apply, st, p);
     }
     NLC_CHECK_LAUNCH("nlc_groupnorm");
+    return NLC_OK;
+}
+
+extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, float eps,
+                                      const float* gamma, const float* beta, const float* scale, const float* shift,
+                                      int ss_stride, int silu, void* out, void* workspace, int dtype,
+                                      const float* stats0, int P0, const float* stats1, int P1, void* stream) {
+    NLC_REQUIRE(dtype == NLC_BF16, "nlc_groupnorm_prestats: bf16 only (the f32 path computes its statistics itself)");
+    NLC_REQUIRE(x0 && out && workspace && stats0 && P0 > 0, "nlc_groupnorm_prestats: null pointer");
+    NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm_prestats: bad dims");
+    NLC_REQUIRE((C1 == 0) == (x1 == nullptr) && (C1 == 0) == (stats1 == nullptr) && (C1 == 0 || P1 > 0),
+                "nlc_groupnorm_prestats: x1 / stats1 / C1 mismatch");
+    const int C = C0 + C1;
+    NLC_REQUIRE(C % groups == 0 && (C / groups) % 8 == 0 && C0 % 8 == 0 && C1 % 8 == 0,
+                "nlc_groupnorm_prestats: group size %d and C0=%d, C1=%d must be multiples of 8", C / groups, C0, C1);
+    NLC_REQUIRE(C / 8 <= NT, "nlc_groupnorm_prestats: C=%d too large for the one-chunk-per-thread apply kernel", C);
+    NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_prestats: scale/shift must come together");
+    NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_prestats: ss_stride < C");
+    GNParams p;
+    fill_params(p, x0, x1, C0, C1, B, HW, groups, dtype);
+    p.eps = eps; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
+    p.silu = silu; p.out = (char*)out; p.ws = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
+    int ppb = p.ps * UNR * 4;
+    while ((int64_t)cdiv(HW, ppb) * B > 8192) ppb *= 2;
+    hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
+                       eps, stat);
+    hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb);
+    NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
     return NLC_OK;
 }

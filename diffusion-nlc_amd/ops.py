@@ -109,8 +109,11 @@ CONV_PROFILE = None
 def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
            pad: Optional[tuple] = None, out_hw: Optional[tuple] = None, upsample2x: bool = False,
            emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
-           act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True) -> torch.Tensor:
-    """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1)."""
+           act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True,
+           emit_stats: bool = True) -> torch.Tensor:
+    """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1).
+    ``emit_stats``: let the epilogue also write the GroupNorm statistics of the output when the launch supports it
+    (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass."""
     lib = _ext.load()
     dt = pw.dtype
     linear = x0.dim() == 2
@@ -156,6 +159,13 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
                  out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC)
+    stats = None
+    if dt == torch.bfloat16 and emit_stats and not out_nchw_f32 and not linear:
+        # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel
+        P = lib.nlc_conv2d_stats_partials(C.byref(d), dtype_enum(dt))
+        if P > 0:
+            stats = torch.empty(B, P, pw.Cout // 8, 2, device=x0.device, dtype=torch.float32)
+            d.stats_out, d.stats_bytes = stats.data_ptr(), stats.numel() * 4
     if dt == torch.bfloat16:                     # split-K scratch for the few-tile / long-K levels (a cheap host query)
         need = lib.nlc_conv2d_workspace_bytes(C.byref(d), dtype_enum(dt))
         if need > 0:
@@ -174,6 +184,8 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
     if linear and not out_nchw_f32:
         out = out.view(B, pw.Cout)
+    if stats is not None:
+        out._nlc_stats = stats                  # consumed by groupnorm(); lives and dies with this tensor object
     return out
 
 
@@ -195,6 +207,7 @@ def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 
 _gn_ws = {}
 _conv_ws = {}
+FUSED_GN_STATS = True        # groupnorm() uses statistics emitted by the producing conv2d() when they are attached
 
 
 def _conv_workspace(device, nbytes: int) -> torch.Tensor:
@@ -242,6 +255,16 @@ def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
         if shift.stride(0) != ss_stride:
             raise ValueError("groupnorm: scale/shift must share a row stride")
     ws = _gn_workspace(x0.device, lib.nlc_groupnorm_workspace_bytes(B, HW, Ctot, groups))
+    if FUSED_GN_STATS and dt == torch.bfloat16 and (Ctot // groups) % 8 == 0 and C0 % 8 == 0 and Ctot // 8 <= 256:
+        s0 = getattr(x0, "_nlc_stats", None)
+        s1 = getattr(x1, "_nlc_stats", None) if x1 is not None else None
+        if s0 is not None and (x1 is None or s1 is not None):
+            # statistics came with the producing convolutions: finalize from their chunk sums + apply (2 passes, not 3)
+            check(lib.nlc_groupnorm_prestats(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
+                                             _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(),
+                                             ws.data_ptr(), dtype_enum(dt), s0.data_ptr(), s0.shape[1], _ptr(s1),
+                                             0 if s1 is None else s1.shape[1], _stream()), "nlc_groupnorm_prestats")
+            return out
     check(lib.nlc_groupnorm(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
                             _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(), ws.data_ptr(),
                             dtype_enum(dt), _stream()), "nlc_groupnorm")

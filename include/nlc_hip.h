@@ -85,12 +85,19 @@ typedef struct nlc_conv_desc {
     int32_t out_mode;
     void* workspace;     /* optional scratch (NULL = none): enables split-K on shapes with few output tiles and a long */
     int64_t workspace_bytes; /* K (the 8x8 / 16x16 levels); size from nlc_conv2d_workspace_bytes, contents undefined   */
+    void* stats_out;     /* optional (NULL = none): GroupNorm statistics of the output, written by the conv's epilogue so    */
+    int64_t stats_bytes; /* that the normalisation that follows (src/unet_adm.py:182-184,206-208) skips its statistics pass: */
+                         /* float [B][P][Cout/8][2] = (sum, sum of squares) of the STORED values per 8-channel chunk and     */
+                         /* partial; P = nlc_conv2d_stats_partials(desc, dtype) must be > 0 (bf16, NHWC, Cout % 128 == 0,    */
+                         /* launches that take the LDS-halo kernel).  Consumed by nlc_groupnorm_prestats.                    */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
 /* bytes of workspace with which nlc_conv2d would split K for this descriptor (0: it would not).  bf16 only - the
  * f32 path keeps a single summation order.  Partial sums are f32 and are added in a fixed order. */
 int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype);
+/* partials per image (P) with which nlc_conv2d would fill stats_out for this descriptor; 0: it would not emit statistics */
+int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype);
 
 /* First-layer convolution for tiny Cin (<=4): reads the sampler state in the reference's
  * own layout (NCHW f32), applies the per-sample input scale c_in[b] (convert_coordinate,
@@ -115,6 +122,15 @@ int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int HW,
                   int groups, float eps, const float* gamma, const float* beta,
                   const float* scale, const float* shift, int ss_stride,
                   int silu, void* out, void* workspace, int dtype, void* stream);
+/* Same, but the statistics come from the producing convolutions' epilogues (nlc_conv_desc.stats_out) instead of a pass
+ * over the input: stats0 / stats1 = float [B][P0|P1][C0/8 | C1/8][2] for x0 / x1.  Requires bf16, (C0+C1)/groups a
+ * multiple of 8 and C0 a multiple of 8 (a group may straddle the two sources).  Partials are added in a fixed order
+ * in f64; var = E[x^2] - E[x]^2 there. */
+int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B, int HW,
+                           int groups, float eps, const float* gamma, const float* beta,
+                           const float* scale, const float* shift, int ss_stride,
+                           int silu, void* out, void* workspace, int dtype,
+                           const float* stats0, int P0, const float* stats1, int P1, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-head softmax attention on token-major tensors (flash style, no TxT matrix in HBM).

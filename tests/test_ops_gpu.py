@@ -263,3 +263,40 @@ def test_row_sumsq_and_quantile():
     # ties everywhere
     z = torch.ones(2, 3, 8, 8) * 3.0
     assert torch.equal(ops.dynamic_threshold(z.to(_dev()), 0.99, 100.0).cpu(), torch.tensor([3.0, 3.0]))
+
+
+def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them():
+    """bf16 LDS-halo conv: the epilogue's per-8-channel (sum, sumsq) partials describe the STORED output exactly enough,
+    and GroupNorm fed with them (two passes) agrees with the three-pass GroupNorm and with the f32 reference."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, Cin, H, W, Cout = 2, 64, 32, 48, 256
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.3 + 0.5                    # non-zero mean: E[x^2]-E[x]^2 is exercised
+    res = torch.randn(B, Cout, H, W, generator=g)
+    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    y = ops.conv2d(_nhwc(x, torch.bfloat16), pw, res=_nhwc(res, torch.bfloat16), act=1)
+    st = getattr(y, "_nlc_stats", None)
+    assert st is not None and st.shape == (B, (H // 16) * (W // 16) * 4, Cout // 8, 2)
+    yf = y.float().cpu()                                              # [B,H,W,C] stored values
+    chunks = yf.view(B, H * W, Cout // 8, 8)
+    ref_sum, ref_sq = chunks.sum(dim=(1, 3)), (chunks.double() ** 2).sum(dim=(1, 3))
+    got = st.double().sum(dim=1).cpu()
+    assert (got[..., 0] - ref_sum.double()).abs().max() < 1e-2 * ref_sum.abs().max().clamp(min=1.0)
+    assert ((got[..., 1] - ref_sq) / ref_sq).abs().max() < 1e-4
+    # a second conv makes the skip source of a concatenated GroupNorm input; 384 channels / 32 groups = 12: not a
+    # multiple of 8 -> falls back; 256 + 256 = 512 -> group size 16, fused
+    y2 = ops.conv2d(_nhwc(x, torch.bfloat16), pw)
+    gamma, beta = torch.randn(2 * Cout, generator=g).to(_dev()), torch.randn(2 * Cout, generator=g).to(_dev())
+    fused = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=True, x1=y2)
+    ops.FUSED_GN_STATS = False
+    try:
+        plain = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=True, x1=y2)
+    finally:
+        ops.FUSED_GN_STATS = True
+    cat = torch.cat([yf, y2.float().cpu()], dim=-1).permute(0, 3, 1, 2)
+    ref = F.silu(F.group_norm(cat, 32, gamma.cpu(), beta.cpu(), eps=1e-5)).permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    assert (fused.float().cpu() - plain.float().cpu()).abs().max().item() <= 2e-2 * scale      # one bf16 ulp of slack
+    assert (fused.float().cpu() - ref).abs().max().item() <= 2e-2 * scale
