@@ -12,8 +12,11 @@
 //   * the tap loop is fully unrolled inside the channel-block loop: per-row input pixel indices and
 //     validity bits for all taps are computed once per tile, a k-step's address work is one
 //     multiply-add per row;
-//   * the epilogue goes through LDS: bias / embedding / residual / scale / activation are applied
-//     with row-contiguous 16-byte residual loads and output stores instead of 2-byte scatters.
+//   * the epilogue runs straight from registers: the MFMA operands are swapped (weights = A) and the weight rows are
+//     permuted at DMA time so that a lane ends up with 16 CONSECUTIVE output channels of one pixel - bias / embedding /
+//     residual / scale / activation, 16-byte residual loads and output stores, no LDS transpose and no barrier
+//     (the short-K 1x1 tiles used to spend a quarter of their time in the LDS-staged epilogue);
+//   * optionally the GroupNorm statistics of the output ride along (see conv_halo.hip).
 #include "common.h"
 #include "conv_params.h"
 
@@ -53,9 +56,20 @@ __device__ __forceinline__ void glds16(const void* gptr, unsigned lds_base) {
                  : "v"(gptr), "s"(lds_base)
                  : "memory");
 }
+// SGPR-base form: address = sbase (wave-uniform) + voff (per lane, 32-bit)
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_base), "s"(sbase)
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-constexpr int EPI_LD = BN + 4;        // f32 row stride of the epilogue staging image (528 B: conflict-free, 16-B aligned)
 
 template <typename T, int TAPS>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p) {
@@ -108,7 +122,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
         }
     }
     const int64_t wrow = (int64_t)TAPS * p.Cin_pad * ES;
-    const char* wbase = p.w + (int64_t)(n0 + lr) * wrow + gc * PER * ES;
+    // LDS row R = lr + 32 i of the weight tile receives output channel (R & 64) + ((R & 15) >> 2) * 16 + ((R >> 4) & 3) * 4
+    // + (R & 3): with the MFMA operands swapped a lane then holds 16 consecutive channels of one pixel (conv_halo.hip)
+    unsigned woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = lr + 32 * i;
+        const int ch = (R & 64) + ((R & 15) >> 2) * 16 + ((R >> 4) & 3) * 4 + (R & 3);
+        woff[i] = (unsigned)((int64_t)ch * wrow + (int64_t)gc * PER * ES);
+    }
+    const char* wtile = p.w + (int64_t)n0 * wrow;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // issue the LDS-DMA of k-step (cb, tap) into `stage` (8 wave-instructions per wave: 4 A, 4 B)
@@ -126,9 +149,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
             const char* ptr = ok ? src + ((int64_t)pix[i][tap] * C + ch) * ES : zero;
             glds16(ptr, a_base + i * 32 * KB_BYTES);
         }
-        const char* wb = wbase + ((int64_t)tap * p.Cin_pad + cb * KBE) * ES;
+        const char* wb = wtile + ((int64_t)tap * p.Cin_pad + cb * KBE) * ES;          // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(wb + (int64_t)i * 32 * wrow, b_base + i * 32 * KB_BYTES);
+        for (int i = 0; i < 4; ++i) glds16_s(woff[i], wb, b_base + i * 32 * KB_BYTES);
     };
 
     const int wm = wave >> 1, wn = wave & 1;
@@ -153,7 +176,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) Mma<T>::run(fb[j], fa[i], acc[i][j]);   // D[channel][pixel]
         }
     };
 
@@ -186,111 +209,113 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
         }
     }
 
+    // ---- after the k-loop lane (fr, fq) of wave (wm, wn) holds, for the 4 pixels m0 + wm*64 + i*16 + fr, the 16
+    //      consecutive output channels n0 + wn*64 + fq*16 + [0, 16): acc[i][j][reg] -> channel offset j*4 + reg
+    const int n = n0 + wn * 64 + fq * 16;
+    if (n >= p.Cout) return;
+    const bool all16 = n + 16 <= p.Cout;
+
     // ---- split-K: raw f32 partial sums, [split][M][Cout]; bias / embedding / residual / activation are applied by
     //      splitk_reduce_kernel, which adds the splits in a fixed order (deterministic)
     if (p.ksplit > 1) {
         float* part = p.partial + (int64_t)blockIdx.y * p.M * p.Cout;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fr;
+            if (m >= p.M) continue;
+            float* dst = part + (int64_t)m * p.Cout + n;
+            if (all16) {                                     // ksplit > 1 implies Cout % 4 == 0: 16-byte aligned
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int m = m0 + wm * 64 + i * 16 + fq * 4 + reg;
-                if (m >= p.M) continue;
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(dst + j * 4) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn * 64 + j * 16 + fr;
-                    if (n < p.Cout) part[(int64_t)m * p.Cout + n] = acc[i][j][reg];
-                }
+                for (int k = 0; k < 16; ++k) if (n + k < p.Cout) dst[k] = acc[i][k >> 2][k & 3];
             }
-        return;
-    }
-    // ---- epilogue
-    if (p.out_mode != NLC_OUT_NHWC) {          // NCHW f32 (last layer only): direct stores
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int m = m0 + wm * 64 + i * 16 + fq * 4 + reg;
-                if (m >= p.M) continue;
-                const int b = m / HWo, rem = m - b * HWo;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn * 64 + j * 16 + fr;
-                    if (n >= p.Cout) continue;
-                    float v = acc[i][j][reg];
-                    if (p.bias) v += p.bias[n];
-                    if (p.emb) v += p.emb[(int64_t)b * p.emb_stride + n];
-                    if (p.res) v += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n);
-                    v = apply_act(v * p.out_scale, p.act);
-                    reinterpret_cast<float*>(p.out)[((int64_t)b * p.Cout + n) * HWo + rem] = v;
-                }
-            }
-        return;
-    }
-    // NHWC: two 64-row halves through an f32 LDS image [64][EPI_LD] (33 KiB; both stages are free now)
-    float* epi = reinterpret_cast<float*>(smem);
-    const bool vec_ok = (p.Cout % PER) == 0;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();
-        if (wm == half) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        epi[(i * 16 + fq * 4 + reg) * EPI_LD + wn * 64 + j * 16 + fr] = acc[i][j][reg];
         }
-        __syncthreads();
-        // each thread owns ONE 16-byte column chunk (cc) for 64*CPR/NTHREADS rows: per-column terms are loaded
-        // once, the row loop is unrolled so several rows' LDS reads / residual loads / stores are in flight together
-        constexpr int CPR = BN / PER;
-        constexpr int RSTEP = NTHREADS / CPR, NIT = 64 / RSTEP;
-        const int cc = tid % CPR, row0 = tid / CPR;
-        const int n = n0 + cc * PER;
-        if (n < p.Cout) {
-            const bool full = vec_ok && (n + PER <= p.Cout);
-            float cbias[PER];
+        return;
+    }
+
+    // ---- epilogue straight from registers
+    const bool vec_ok = (p.Cout % PER) == 0;
+    const bool full = vec_ok && all16;
+    constexpr int NCH = 16 / PER;
+    float cbias[16];
 #pragma unroll
-            for (int k = 0; k < PER; ++k) cbias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+    for (int k = 0; k < 16; ++k) cbias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+    float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};            // GroupNorm statistics: two 8-channel chunks, 4 pixels
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int row = row0 + it * RSTEP;
-                const int m = m0 + half * 64 + row;
-                if (m >= p.M) continue;
-                float v[PER];
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        if (m >= p.M) continue;
+        const int b = m / HWo;
+        float v[16];
 #pragma unroll
-                for (int k = 0; k < PER; k += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(epi + row * EPI_LD + cc * PER + k);
-                    v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg] + cbias[j * 4 + reg];
+        if (p.emb) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (n + k < p.Cout) v[k] += p.emb[(int64_t)b * p.emb_stride + n + k];
+        }
+        if (p.res) {
+            const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
+            if (full) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    float rr[PER];
+                    chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rp + c * PER), rr);
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) v[c * PER + k] += rr[k];
                 }
-                const int b = m / HWo;
-                float r[PER];
+            } else {
 #pragma unroll
-                for (int k = 0; k < PER; ++k) r[k] = 0.f;
-                if (p.res) {
-                    const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
-                    if (full) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rp), r);
-                    else {
+                for (int k = 0; k < 16; ++k) if (n + k < p.Cout) v[k] += ElemTraits<T>::load(rp + k);
+            }
+        }
 #pragma unroll
-                        for (int k = 0; k < PER; ++k) r[k] = (n + k < p.Cout) ? ElemTraits<T>::load(rp + k) : 0.f;
+        for (int k = 0; k < 16; ++k) v[k] = apply_act(v[k] * p.out_scale, p.act);
+        if (p.out_mode == NLC_OUT_NHWC) {
+            T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
+            if (full) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const uint4 pk = f32_to_chunk<T>(v + c * PER);
+                    *reinterpret_cast<uint4*>(op + c * PER) = pk;
+                    if constexpr (sizeof(T) == 2) {
+                        if (p.stats) {
+                            const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float lo = __uint_as_float(wds[q] << 16), hi = __uint_as_float(wds[q] & 0xffff0000u);
+                                gsum[c] += lo; gsum[c] += hi;
+                                gsq[c] = fmaf(lo, lo, gsq[c]); gsq[c] = fmaf(hi, hi, gsq[c]);
+                            }
+                        }
                     }
                 }
+            } else {
 #pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    float x = v[k];
-                    if (p.bias) x += cbias[k];
-                    if (p.emb) x += (n + k < p.Cout) ? p.emb[(int64_t)b * p.emb_stride + n + k] : 0.f;
-                    if (p.res) x += r[k];
-                    v[k] = apply_act(x * p.out_scale, p.act);
-                }
-                T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
-                if (full) *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
-                else {
+                for (int k = 0; k < 16; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
+            }
+        } else {                                             // NCHW f32 (last layer): consecutive lanes = consecutive pixels
+            const int rem = m - b * HWo;
 #pragma unroll
-                    for (int k = 0; k < PER; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
-                }
+            for (int k = 0; k < 16; ++k)
+                if (n + k < p.Cout) reinterpret_cast<float*>(p.out)[((int64_t)b * p.Cout + n + k) * HWo + rem] = v[k];
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (p.stats) {       // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
+            float r4[4] = {gsum[0], gsq[0], gsum[1], gsq[1]};
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r4[q] += __shfl_xor(r4[q], o, 64);
+            if (fr == 0) {
+                const int b = m0 / HWo;
+                const int part = ((m0 - b * HWo) / BM) * 2 + wm;
+                float* dst = p.stats + (((int64_t)b * p.stats_P + part) * (p.Cout >> 3) + (n >> 3)) * 2;
+                *reinterpret_cast<float4*>(dst) = float4{r4[0], r4[1], r4[2], r4[3]};
             }
         }
     }
@@ -366,6 +391,19 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     if (s > ncb / min_cb) s = ncb / min_cb;
     if (s > 8) s = 8;
     return s < 2 ? 1 : s;
+}
+
+// GroupNorm statistics ride along on the fast path when every 128-pixel tile lies inside one image, the N-tiles are
+// whole, the output is bf16 NHWC and K is not split (the split-K reduce kernel has no statistics epilogue)
+int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
+    if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
+    const bool k3 = p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1;
+    const bool k1 = p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0;
+    if (p.stride != 1 || !(k3 || k1)) return 0;
+    const int HWo = p.Hout * p.Wout;
+    if (HWo % BM) return 0;
+    if (nlc_conv_fast_ksplit(p, dtype) > 1) return 0;
+    return (HWo / BM) * 2;
 }
 
 // returns NLC_EUNSUPPORTED when the shape is not one the fast path handles (caller falls back)

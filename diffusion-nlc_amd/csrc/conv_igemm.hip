@@ -263,7 +263,11 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     if (force_generic) return 0;
     KParams p{};
     geometry_only(d, p);
-    return nlc_conv_halo_stats_partials(p, dtype);
+    const int P = nlc_conv_halo_stats_partials(p, dtype);
+    if (P > 0) return P;
+    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
+    if (!(p.Hout == HL && p.Wout == WL)) return 0;                // generic kernel: no statistics epilogue
+    return nlc_conv_fast_stats_partials(p, dtype);
 }
 
 extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
@@ -313,15 +317,18 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     if (!force_generic && p.Hout == HL && p.Wout == WL) {
+        int Pfast = 0;
         if (d->stats_out) {
-            const int P = nlc_conv_halo_stats_partials(p, dtype);
+            const int Phalo = nlc_conv_halo_stats_partials(p, dtype);
+            Pfast = Phalo > 0 ? 0 : nlc_conv_fast_stats_partials(p, dtype);
+            const int P = Phalo > 0 ? Phalo : Pfast;
             NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
             NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / 8) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
             p.stats = (float*)d->stats_out; p.stats_P = P;
         }
         int rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
-        p.stats = nullptr; p.stats_P = 0;
+        if (!Pfast) { p.stats = nullptr; p.stats_P = 0; }
         if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace
             const int ks = nlc_conv_fast_ksplit(p, dtype);
             if (ks > 1 && d->workspace_bytes >= (int64_t)ks * p.M * p.Cout * (int64_t)sizeof(float)) {

@@ -23,7 +23,7 @@ struct KParams {
     int M, MT, NT;
     int ksplit;         // conv_fast only: >1 = split the channel blocks over blockIdx.y, raw f32 partials to `partial`
     float* partial;     // [ksplit][M][Cout] f32 (caller workspace); reduced + epilogue by splitk_reduce_kernel
-    float* stats;       // conv_halo only (bf16, NHWC out, Cout % 128 == 0) or NULL: [B][stats_P][Cout/8][2] = per 8-channel
+    float* stats;       // conv_halo / conv_fast (bf16, NHWC out, Cout % 128 == 0) or NULL: [B][stats_P][Cout/8][2] = per 8-channel
     int stats_P;        //   chunk (sum, sum of squares) of the STORED (bf16-rounded) outputs, one partial per (patch, M-wave)
 };
 
@@ -31,6 +31,8 @@ struct KParams {
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);
 // split-K policy for the shapes conv_fast takes (few output tiles, long K): number of splits, 1 = none
 int nlc_conv_fast_ksplit(const KParams& p, int dtype);
+// conv_fast.hip: same for the fast path (0 when K would be split or a tile could straddle two images)
+int nlc_conv_fast_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: partials per image the halo kernel would emit GroupNorm statistics with for this launch (0: it would not)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: 3x3 with the input halo resident in LDS; same return convention

@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from diffusion_nlc_amd import ops  # noqa: E402
 
+SILU = True
 SHAPES = [  # (H, C0, C1)
     (256, 256, 0), (256, 512, 0), (256, 256, 256), (128, 256, 0), (128, 512, 0), (128, 512, 256), (64, 512, 0), (64, 1024, 0),
     (32, 512, 0), (32, 1024, 0), (16, 1024, 0), (16, 1024, 1024), (8, 1024, 0),
@@ -24,7 +25,10 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-silu", action="store_true", help="normalise only (memory-side rate of the same access pattern)")
     args = ap.parse_args()
+    global SILU
+    SILU = not args.no_silu
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     tot_ms = tot_b = 0.0
@@ -34,12 +38,12 @@ def main():
         C = c0 + c1
         g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
         for _ in range(3):
-            ops.groupnorm(x0, g, b, groups=32, eps=1e-5, silu=True, x1=x1)
+            ops.groupnorm(x0, g, b, groups=32, eps=1e-5, silu=SILU, x1=x1)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            ops.groupnorm(x0, g, b, groups=32, eps=1e-5, silu=True, x1=x1)
+            ops.groupnorm(x0, g, b, groups=32, eps=1e-5, silu=SILU, x1=x1)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
