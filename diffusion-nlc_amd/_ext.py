@@ -92,7 +92,8 @@ SIGNATURES = {
     "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
-    "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "nlc_conv_first_stats_partials": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),
     "nlc_groupnorm_workspace_bytes": (C.c_int64, [_i, _i, _i, _i]),
     "nlc_groupnorm": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "nlc_groupnorm_prestats": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),

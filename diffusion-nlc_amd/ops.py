@@ -200,8 +200,15 @@ def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
     if cin_w != Cin or k * k != taps:
         raise ValueError("conv_first: weight shape mismatch")
     out = torch.empty(B, H, W, Cout, device=x_nchw.device, dtype=dtype)
+    stats = None
+    P = lib.nlc_conv_first_stats_partials(Cin, H, W, Cout, k, k, dtype_enum(dtype))
+    if P > 0:
+        stats = torch.empty(B, P, Cout // 8, 2, device=x_nchw.device, dtype=torch.float32)
     check(lib.nlc_conv_first(x_nchw.data_ptr(), _ptr(in_scale), w.data_ptr(), _ptr(bias), out.data_ptr(),
-                             B, Cin, H, W, Cout, k, k, dtype_enum(dtype), _stream()), "nlc_conv_first")
+                             B, Cin, H, W, Cout, k, k, dtype_enum(dtype), _ptr(stats),
+                             0 if stats is None else stats.numel() * 4, _stream()), "nlc_conv_first")
+    if stats is not None:
+        out._nlc_stats = stats
     return out
 
 

@@ -107,7 +107,11 @@ int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype);
 int nlc_conv_first(const float* x_nchw, const float* in_scale /*[B] or NULL*/,
                    const float* w, const float* bias, void* out_nhwc,
                    int B, int Cin, int H, int W, int Cout, int KH, int KW,
-                   int dtype, void* stream);
+                   int dtype, void* stats_out /* or NULL */, int64_t stats_bytes, void* stream);
+/* stats_out: GroupNorm statistics of the output, float [B][P][Cout/8][2] as in nlc_conv_desc.stats_out, with
+ * P = nlc_conv_first_stats_partials(...) > 0 (bf16, KH*KW*Cin <= 32, Cout <= 256 and a multiple of 16, H*W a
+ * multiple of 64: the launches that take the matrix-core kernel). */
+int nlc_conv_first_stats_partials(int Cin, int H, int W, int Cout, int KH, int KW, int dtype);
 
 /* ------------------------------------------------------------------------------------
  * GroupNorm (+ optional FiLM scale/shift, + optional SiLU), statistics in f32.

@@ -241,6 +241,21 @@ def test_conv_first(dtype):
     wp = w.permute(0, 2, 3, 1).reshape(40, 9, 3).contiguous().to(_dev())
     got = ops.conv_first(x.to(_dev()), wp, b.to(_dev()), dtype, in_scale=sc.to(_dev()))
     _close(got.permute(0, 3, 1, 2), ref, 1e-5 if dtype == torch.float32 else 1e-2, "conv_first")
+    # ADM-like first layer: whole 64-pixel tiles, 256 channels -> bf16 takes the matrix-core kernel and emits
+    # GroupNorm statistics of the stored output
+    x = torch.randn(2, 3, 32, 64, generator=g)
+    w = torch.randn(256, 3, 3, 3, generator=g) / 5
+    b = torch.randn(256, generator=g) * 0.1
+    ref = F.conv2d(x * sc[:, None, None, None], w, b, padding=1)
+    wp = w.permute(0, 2, 3, 1).reshape(256, 9, 3).contiguous().to(_dev())
+    got = ops.conv_first(x.to(_dev()), wp, b.to(_dev()), dtype, in_scale=sc.to(_dev()))
+    _close(got.permute(0, 3, 1, 2), ref, 1e-5 if dtype == torch.float32 else 1e-2, "conv_first 256")
+    st = getattr(got, "_nlc_stats", None)
+    assert (st is not None) == (dtype == torch.bfloat16)
+    if st is not None:
+        ch = got.float().cpu().view(2, 32 * 64, 32, 8)
+        assert (st.double().sum(1).cpu()[..., 0] - ch.double().sum(dim=(1, 3))).abs().max() < 5e-2
+        assert ((st.double().sum(1).cpu()[..., 1] - (ch.double() ** 2).sum(dim=(1, 3))) / (ch.double() ** 2).sum(dim=(1, 3))).abs().max() < 1e-4
 
 
 def test_row_sumsq_and_quantile():
