@@ -78,7 +78,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
     constexpr int KBE = Mma<T>::KBE;
     constexpr int ES = (int)sizeof(T);
     constexpr int KW = TAPS == 9 ? 3 : 1;
-    constexpr int PAD = TAPS == 9 ? 1 : 0;
 
     const int nblk = p.MT * p.NT;
     int bid = blockIdx.x;
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
         if (mv) { b = m / HWo; const int rem = m - b * HWo; oy = rem / p.Wout; ox = rem - oy * p.Wout; }
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            int iy = oy + t / KW - PAD, ix = ox + t % KW - PAD;
+            int iy = oy * p.stride + t / KW - p.pad_t, ix = ox * p.stride + t % KW - p.pad_l;
             const bool ok = mv && iy >= 0 && iy < HL && ix >= 0 && ix < WL;
             if (p.ups) { iy >>= 1; ix >>= 1; }
             pix[i][t] = ok ? (b * p.Hin + iy) * p.Win + ix : 0;
@@ -375,16 +374,25 @@ int launch_fast(const KParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// Split-K policy: bf16 only (the f32 parity path keeps one summation order), shapes with fewer output tiles than
+// Shapes of the fast path: 3x3 (any stride, any top/left padding: the far side is zero-filled by the tap tables, so
+// the stride-2 Downsample convs of ADM / the sigma nets and the asymmetric-pad ones of the simple UNet qualify) and
+// unpadded stride-1 1x1.
+static bool fast_shape(const KParams& p) {
+    const bool k3 = p.KH == 3 && p.KW == 3;
+    const bool k1 = p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0 && p.stride == 1;
+    if (!(k3 || k1)) return false;
+    if (p.ups && p.stride != 1) return false;
+    return (int64_t)p.B * p.Hin * p.Win < (1ll << 31);
+}
+
+// Split-K policy (the caller opts in by passing a workspace; the f32 parity path never does): shapes with fewer output tiles than
 // 2 per CU and a long K; at least 2 channel blocks (18 / 2 k-steps) per split, at most 8 splits, aiming at >= 2
 // workgroups per CU (the 8x8 / 16x16 levels of ADM-256 at B = 16 have 64 / 256 tiles for 144-288 k-steps).
 int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
-    if (dtype != NLC_BF16 || (p.Cout & 3)) return 1;
-    const bool k3 = p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1;
-    const bool k1 = p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0;
-    if (p.stride != 1 || !(k3 || k1)) return 1;
+    if ((p.Cout & 3) || !fast_shape(p)) return 1;
+    const bool k3 = p.KH == 3;
     const int tiles = p.MT * p.NT;
-    const int ncb = p.Cin_pad / Mma<bf16_raw>::KBE;
+    const int ncb = p.Cin_pad / (dtype == NLC_BF16 ? Mma<bf16_raw>::KBE : Mma<float>::KBE);
     if (tiles >= 512) return 1;
     int s = cdiv(512, tiles);
     const int min_cb = k3 ? 2 : 8;                   // >= 18 (3x3) / 8 (1x1) k-steps per split
@@ -396,10 +404,7 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
 // GroupNorm statistics ride along on the fast path when every 128-pixel tile lies inside one image, the N-tiles are
 // whole, the output is bf16 NHWC and K is not split (the split-K reduce kernel has no statistics epilogue)
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
-    if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
-    const bool k3 = p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1;
-    const bool k1 = p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0;
-    if (p.stride != 1 || !(k3 || k1)) return 0;
+    if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0 || !fast_shape(p)) return 0;
     const int HWo = p.Hout * p.Wout;
     if (HWo % BM) return 0;
     if (nlc_conv_fast_ksplit(p, dtype) > 1) return 0;
@@ -408,10 +413,8 @@ int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
 
 // returns NLC_EUNSUPPORTED when the shape is not one the fast path handles (caller falls back)
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream) {
-    const bool k3 = p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1;
-    const bool k1 = p.KH == 1 && p.KW == 1 && p.pad_t == 0 && p.pad_l == 0;
-    if (p.stride != 1 || !(k3 || k1)) return NLC_EUNSUPPORTED;
-    if ((int64_t)p.B * p.Hin * p.Win >= (1ll << 31)) return NLC_EUNSUPPORTED;
+    if (!fast_shape(p)) return NLC_EUNSUPPORTED;
+    const bool k3 = p.KH == 3;
     if (dtype == NLC_BF16) return k3 ? launch_fast<bf16_raw, 9>(p, stream) : launch_fast<bf16_raw, 1>(p, stream);
     return k3 ? launch_fast<float, 9>(p, stream) : launch_fast<float, 1>(p, stream);
 }

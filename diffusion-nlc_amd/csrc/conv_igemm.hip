@@ -242,8 +242,6 @@ extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype)
     p.ups = d->upsample2x ? 1 : 0;
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
-    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
-    if (!(p.Hout == HL && p.Wout == WL)) return 0;
     const int ks = nlc_conv_fast_ksplit(p, dtype);
     return ks > 1 ? (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) : 0;
 }
@@ -265,8 +263,6 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     geometry_only(d, p);
     const int P = nlc_conv_halo_stats_partials(p, dtype);
     if (P > 0) return P;
-    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
-    if (!(p.Hout == HL && p.Wout == WL)) return 0;                // generic kernel: no statistics epilogue
     return nlc_conv_fast_stats_partials(p, dtype);
 }
 
@@ -316,7 +312,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     // odd kernels, cropped outputs) the generic gather kernel.  NLC_CONV_GENERIC=1 forces the latter (A/B runs).
     static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
-    if (!force_generic && p.Hout == HL && p.Wout == WL) {
+    (void)HL; (void)WL;
+    if (!force_generic) {
         int Pfast = 0;
         if (d->stats_out) {
             const int Phalo = nlc_conv_halo_stats_partials(p, dtype);

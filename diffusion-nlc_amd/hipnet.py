@@ -213,7 +213,9 @@ class EmbBank:
         self._off += n
         return off, n
 
-    def finalize(self, device):
+    def finalize(self, device, allow_split: bool = False):
+        """``allow_split``: the (f32) GEMM may split K - set by bf16 models; f32 models keep one summation order."""
+        self.allow_split = allow_split
         if self._w:
             self.packed = ops.pack_conv(torch.cat(self._w, 0), torch.cat(self._b, 0), torch.float32, device)
         self._w, self._b = [], []
@@ -221,7 +223,7 @@ class EmbBank:
     def __call__(self, emb_in: torch.Tensor) -> Optional[torch.Tensor]:
         if self.packed is None:
             return None
-        return ops.conv2d(emb_in, self.packed)
+        return ops.conv2d(emb_in, self.packed, allow_split=getattr(self, "allow_split", False))
 
 
 class SigmaHead:
@@ -232,7 +234,8 @@ class SigmaHead:
     flattened in the reference's NCHW order by the layout kernel.
     """
 
-    def __init__(self, sd, device, act: int):
+    def __init__(self, sd, device, act: int, allow_split: bool = False):
+        self.allow_split = allow_split
         w, b = sd["fc_layer.1.weight"].double(), sd["fc_layer.1.bias"].double()
         g, beta = sd["fc_layer.2.weight"].double(), sd["fc_layer.2.bias"].double()
         mean, var = sd["fc_layer.2.running_mean"].double(), sd["fc_layer.2.running_var"].double()
@@ -243,7 +246,7 @@ class SigmaHead:
 
     def __call__(self, h_nhwc: torch.Tensor) -> torch.Tensor:
         flat = ops.nhwc_to_nchw_f32(h_nhwc).view(h_nhwc.shape[0], -1)
-        h = ops.conv2d(flat, self.fc, act=self.act)
+        h = ops.conv2d(flat, self.fc, act=self.act, allow_split=self.allow_split)
         return ops.conv2d(h, self.final).view(-1)          # r[b]
 
 

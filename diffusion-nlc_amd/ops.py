@@ -110,10 +110,12 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
            pad: Optional[tuple] = None, out_hw: Optional[tuple] = None, upsample2x: bool = False,
            emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
            act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True,
-           emit_stats: bool = True) -> torch.Tensor:
+           emit_stats: bool = True, allow_split: bool = False) -> torch.Tensor:
     """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1).
     ``emit_stats``: let the epilogue also write the GroupNorm statistics of the output when the launch supports it
-    (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass."""
+    (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass.
+    ``allow_split``: an f32 GEMM may split K (bf16 ones always may); the f32 parity path leaves it off so that its
+    summation order never depends on the shape."""
     lib = _ext.load()
     dt = pw.dtype
     linear = x0.dim() == 2
@@ -166,7 +168,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         if P > 0:
             stats = torch.empty(B, P, pw.Cout // 8, 2, device=x0.device, dtype=torch.float32)
             d.stats_out, d.stats_bytes = stats.data_ptr(), stats.numel() * 4
-    if dt == torch.bfloat16:                     # split-K scratch for the few-tile / long-K levels (a cheap host query)
+    if dt == torch.bfloat16 or allow_split:      # split-K scratch for the few-tile / long-K levels (a cheap host query)
         need = lib.nlc_conv2d_workspace_bytes(C.byref(d), dtype_enum(dt))
         if need > 0:
             ws = _conv_workspace(x0.device, need)

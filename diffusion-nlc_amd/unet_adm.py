@@ -236,7 +236,7 @@ class UNetModel(HipModule):
         P.inp = [make(l) for l in blocks_in]
         P.mid = make(mid)
         P.out = [make(l) for l in blocks_out]
-        bank.finalize(device)
+        bank.finalize(device, allow_split=dtype == torch.bfloat16)
         P.bank = bank
         P.out_norm = Norm(sd, "out.0", device, GN_GROUPS, GN_EPS)
         P.out_conv = pack(sd, "out.2", dtype, device)
@@ -245,8 +245,9 @@ class UNetModel(HipModule):
     # ---- execution -----------------------------------------------------------------------------
     def _emb(self, P, t):
         temb = ops.timestep_embedding(t, P.freqs, sin_first=False)          # cos || sin
-        e = ops.conv2d(temb, P.te0, act=ACT_SILU)                            # Linear -> SiLU
-        e = ops.conv2d(e, P.te2, act=ACT_SILU)                               # Linear; every consumer starts with SiLU(emb)
+        sp = self.compute_dtype == torch.bfloat16                            # f32 GEMMs of a bf16 model may split K
+        e = ops.conv2d(temb, P.te0, act=ACT_SILU, allow_split=sp)            # Linear -> SiLU
+        e = ops.conv2d(e, P.te2, act=ACT_SILU, allow_split=sp)               # Linear; every consumer starts with SiLU(emb)
         return P.bank(e)
 
     @staticmethod
@@ -372,7 +373,7 @@ class SigmaModel(HipModule):
             P.blocks.append((pad, _ResBlock(sd, res, dtype, device, None, False),
                              _Attention(sd, attn, dtype, device, self.heads, self.new_order) if attn else None,
                              pack(sd, down + ".op", dtype, device)))
-        P.head = SigmaHead(sd, device, ACT_GELU)
+        P.head = SigmaHead(sd, device, ACT_GELU, allow_split=dtype == torch.bfloat16)
         return P
 
     def run_nhwc(self, h: torch.Tensor) -> torch.Tensor:

@@ -176,7 +176,7 @@ class Model(HipModule):
         P.up = [([(mk(p), _AttnBlock(sd, a, dtype, device) if a else None) for p, ci, co, a in blocks],
                  (pack(sd, us + ".conv", dtype, device) if self.resamp_with_conv else "nearest") if us else None)
                 for lvl, blocks, us, cin in up]
-        bank.finalize(device)
+        bank.finalize(device, allow_split=dtype == torch.bfloat16)
         P.bank = bank
         P.norm_out = Norm(sd, "norm_out", device, GN_GROUPS, GN_EPS)
         P.conv_out = pack(sd, "conv_out", dtype, device)
@@ -288,7 +288,7 @@ class SigmaModel(HipModule):
         layout, _ = self._layout()
         P.blocks = [(pad, _ResnetBlock(sd, res, dtype, device, None), _AttnBlock(sd, attn, dtype, device) if attn else None,
                      pack(sd, down + ".conv", dtype, device)) for pad, res, attn, down in layout]
-        P.head = SigmaHead(sd, device, ACT_GELU)
+        P.head = SigmaHead(sd, device, ACT_GELU, allow_split=dtype == torch.bfloat16)
         return P
 
     def run_nhwc(self, h):

@@ -93,8 +93,9 @@ typedef struct nlc_conv_desc {
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
-/* bytes of workspace with which nlc_conv2d would split K for this descriptor (0: it would not).  bf16 only - the
- * f32 path keeps a single summation order.  Partial sums are f32 and are added in a fixed order. */
+/* bytes of workspace with which nlc_conv2d would split K for this descriptor (0: it would not).  Passing the workspace
+ * is the caller's opt-in: with none, one summation order is kept (the f32 parity path).  Partial sums are f32 and are
+ * added in a fixed order. */
 int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype);
 /* partials per image (P) with which nlc_conv2d would fill stats_out for this descriptor; 0: it would not emit statistics */
 int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype);
