@@ -22,7 +22,7 @@
 
 namespace {
 
-__device__ uint4 g_zero_page[8];      // 128 zero bytes: source of every out-of-image / out-of-channel chunk
+__device__ uint4 g_zero_page[8];      // 128 zero bytes: source of every out-of-image / out-of-channel chunk (and of a missing bias)
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_raw> {
@@ -238,12 +238,70 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
     const bool vec_ok = (p.Cout % PER) == 0;
     const bool full = vec_ok && all16;
     constexpr int NCH = 16 / PER;
+    // branch-free loads (clamped index, zero page for a missing bias): a per-element "if (in range) load" compiles to
+    // load; s_waitcnt vmcnt(0) pairs, one full memory latency each
     float cbias[16];
+    {
+        const float* zf = reinterpret_cast<const float*>(g_zero_page);
+        const float* bp = p.bias ? p.bias : zf;
+        const int hb = p.bias ? 1 : 0, last = p.Cout - 1;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) cbias[k] = (p.bias && n + k < p.Cout) ? p.bias[n + k] : 0.f;
+        for (int k = 0; k < 16; ++k) { const float vb = bp[hb ? min(n + k, last) : k]; cbias[k] = (n + k < p.Cout) ? vb : 0.f; }
+    }
     float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};            // GroupNorm statistics: two 8-channel chunks, 4 pixels
+    bool done = false;
+    if constexpr (sizeof(T) == 2) {
+        // hot path (bf16, whole 16-channel slice, NHWC, no per-image embedding): option switches hoisted out of the
+        // element loops (see conv_halo.hip: the general path costs ~19 VALU per output element)
+        if (full && p.out_mode == NLC_OUT_NHWC && !p.emb) {
+            const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+            const float sc = p.out_scale;
+            const int act = p.act;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + fr;
+                if (m >= p.M) continue;
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg] + cbias[j * 4 + reg];
+                if (has_res) {
+                    const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
+                    const uint4 r0 = *reinterpret_cast<const uint4*>(rp), r1 = *reinterpret_cast<const uint4*>(rp + 8);
+                    float rr[16];
+                    chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] += rr[k];
+                }
+                if (sc != 1.0f) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] *= sc;
+                }
+                if (act == NLC_ACT_SILU) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = silu_f(v[k]);
+                } else if (act == NLC_ACT_GELU) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = gelu_erf(v[k]);
+                }
+                T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
+                *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
+                *reinterpret_cast<uint4*>(op + 8) = f32_to_chunk<T>(v + 8);
+                if (has_stats) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        gsum[0] += v[k]; gsq[0] = fmaf(v[k], v[k], gsq[0]);
+                        gsum[1] += v[8 + k]; gsq[1] = fmaf(v[8 + k], v[8 + k], gsq[1]);
+                    }
+                }
+            }
+            done = true;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        if (done) break;
         const int m = m0 + wm * 64 + i * 16 + fr;
         if (m >= p.M) continue;
         const int b = m / HWo;
@@ -253,8 +311,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg] + cbias[j * 4 + reg];
         if (p.emb) {
+            const float* ep = p.emb + (int64_t)b * p.emb_stride;
+            float ev[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (n + k < p.Cout) v[k] += p.emb[(int64_t)b * p.emb_stride + n + k];
+            for (int k = 0; k < 16; ++k) ev[k] = ep[min(n + k, p.Cout - 1)];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] += (n + k < p.Cout) ? ev[k] : 0.f;
         }
         if (p.res) {
             const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
@@ -305,11 +367,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
     }
     if constexpr (sizeof(T) == 2) {
         if (p.stats) {       // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
-            float r4[4] = {gsum[0], gsq[0], gsum[1], gsq[1]};
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) r4[q] += __shfl_xor(r4[q], o, 64);
+            // sum over the 16 pixel lanes of a DPP row, VALU only (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
+            auto row16_sum = [](float x) {
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+                return x;
+            };
+            const float r4[4] = {row16_sum(gsum[0]), row16_sum(gsq[0]), row16_sum(gsum[1]), row16_sum(gsq[1])};
             if (fr == 0) {
                 const int b = m0 / HWo;
                 const int part = ((m0 - b * HWo) / BM) * 2 + wm;

@@ -97,11 +97,18 @@ struct TileH { int tb, y0, x0, n0; };
 #endif
 __device__ unsigned long long g_halo_clock[4];     // {s_memtime, s_memrealtime} at loop start / end of workgroup 0, wave 0
 __device__ unsigned long long g_halo_stamps[8][8];
+__device__ unsigned long long g_halo_epi[8][6];    // inside the epilogue of tile 1: start, cadd loads issued, pixel loop done, stats done, acc re-initialised
+__device__ unsigned long long g_halo_tile[8][4];   // per wave: s_memtime before / after the epilogues of tiles 1 and 2 of workgroup 0
 #define STAMP(i) do { if (stamp_on && tap == HALO_STAMP_TAP) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define STAMP_FLUSH() do { if (stamp_on && tap == HALO_STAMP_TAP && lane == 0) { for (int q_ = 0; q_ < 8; ++q_) g_halo_stamps[wave][q_] = st[q_]; } } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #define STAMP_FLUSH() do {} while (0)
+#endif
+#ifdef HALO_STAMP
+#define ESTAMP(i) do { if (blockIdx.x == 0 && lane == 0 && estamp_on) { __builtin_amdgcn_sched_barrier(0); g_halo_epi[wave][i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define ESTAMP(i) do {} while (0)
 #endif
 
 template <typename T>
@@ -247,15 +254,49 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // reference's order instead - conv sum, then + bias, then + embedding, then + residual - so that it rounds like
     // F.conv2d(x, w, b) + emb + res does; there the accumulators start at zero.
     constexpr bool FOLD = sizeof(T) == 2;
-    auto load_cadd = [&](const TileH& t, float (&cadd)[16]) {
+    // Branch-free on purpose: with a per-element "if (in range) load" the compiler emitted 16 x (global_load_dword;
+    // s_waitcnt vmcnt(0)) - every load paid a full memory latency AND drained the in-flight weight DMAs and stores;
+    // in-kernel stamps showed the epilogue at 11-12 k cycles of a 68 k-cycle tile.  Now: clamped indices (the zero page
+    // stands in for a missing bias / embedding), 32 independent loads, one wait.
+    const float* zf = reinterpret_cast<const float*>(g_zero_page_h);
+    auto load_cadd2 = [&](const TileH& t, float (&cb_)[16], float (&ce_)[16]) {
         const int n = t.n0 + wn * 64 + fq * 16;
+        const float* bp = p.bias ? p.bias : zf;
+        const float* ep = p.emb ? p.emb + (int64_t)t.tb * p.emb_stride : zf;
+        const int hb = p.bias ? 1 : 0, he = p.emb ? 1 : 0, last = p.Cout - 1;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+            const int c = min(n + k, last);
+            const float vb = bp[hb ? c : k], ve = ep[he ? c : k];
             const bool okc = n + k < p.Cout;
-            float v = (p.bias && okc) ? p.bias[n + k] : 0.f;
-            if (p.emb && okc) v += p.emb[(int64_t)t.tb * p.emb_stride + n + k];
-            cadd[k] = FOLD ? v : 0.f;
+            cb_[k] = okc ? vb : 0.f;
+            ce_[k] = okc ? ve : 0.f;
         }
+    };
+    const bool bias_vec = p.bias && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) && !p.emb;   // 4 x 16-byte loads suffice
+    auto load_cadd = [&](const TileH& t, float (&cadd)[16]) {
+        const int n = t.n0 + wn * 64 + fq * 16;
+        if (FOLD && bias_vec && n + 16 <= p.Cout) {          // every VMEM instruction costs its wave ~60-100 issue cycles
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n + q * 4);
+                cadd[q * 4] = b4.x; cadd[q * 4 + 1] = b4.y; cadd[q * 4 + 2] = b4.z; cadd[q * 4 + 3] = b4.w;
+            }
+            return;
+        }
+        float ce_[16];
+        load_cadd2(t, cadd, ce_);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cadd[k] = FOLD ? cadd[k] + ce_[k] : 0.f;
+    };
+    // sum over the 16 lanes of a DPP row (= the 16 pixels fr of one quarter-wave), result in every lane; VALU only
+    // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) - a __shfl_xor is a ds_bpermute, ~100 cycles each
+    auto row16_sum = [&](float x) {
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+        return x;
     };
     auto init_acc = [&](const float (&cadd)[16]) {
 #pragma unroll
@@ -264,16 +305,74 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cadd[j * 4], cadd[j * 4 + 1], cadd[j * 4 + 2], cadd[j * 4 + 3]};
     };
     auto epilogue = [&](const TileH& t, const TileH& nx) {
+#ifdef HALO_STAMP
+        const bool estamp_on = (tl - wi) / gx == 1;
+#endif
+        ESTAMP(0);
         float cnext[16];
         load_cadd(nx, cnext);                        // in flight while this tile is stored
+        ESTAMP(1);
         const int n = t.n0 + wn * 64 + fq * 16;
         float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};        // this lane's two 8-channel chunks over its 4 pixels
-        if (n < p.Cout) {
+        bool done = false;
+        if constexpr (FOLD) {
+            // hot path (bf16, whole 16-channel slice, NHWC): the option switches are hoisted out of the element loops;
+            // measured with stamps, the general path below spent ~9 k cycles per tile on ~19 VALU per output element
+            if (vec_ok && n + 16 <= p.Cout && p.out_mode == NLC_OUT_NHWC) {
+                const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+                const float sc = p.out_scale;
+                const int act = p.act;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = ((int64_t)t.tb * p.Hin + t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg];
+                    if (has_res) {
+                        const T* rp = reinterpret_cast<const T*>(p.res) + m * p.Cout + n;
+                        const uint4 r0 = *reinterpret_cast<const uint4*>(rp), r1 = *reinterpret_cast<const uint4*>(rp + 8);
+                        float rr[16];
+                        chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) v[k] += rr[k];
+                    }
+                    if (sc != 1.0f) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) v[k] *= sc;
+                    }
+                    if (act == NLC_ACT_SILU) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) v[k] = silu_f(v[k]);
+                    } else if (act == NLC_ACT_GELU) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) v[k] = gelu_erf(v[k]);
+                    }
+                    T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
+#ifndef HALO_NO_STORE                                          /* timing diagnostics only (tools/halo_variant.sh) */
+                    *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
+                    *reinterpret_cast<uint4*>(op + 8) = f32_to_chunk<T>(v + 8);
+#endif
+                    if (has_stats) {     // of the f32 values: their bf16 rounding is zero-mean, 2^-9 relative per element
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            gsum[0] += v[k]; gsq[0] = fmaf(v[k], v[k], gsq[0]);
+                            gsum[1] += v[8 + k]; gsq[1] = fmaf(v[8 + k], v[8 + k], gsq[1]);
+                        }
+                    }
+                }
+                done = true;
+            }
+        }
+        if (!done && n < p.Cout) {
             const bool full = vec_ok && (n + 16 <= p.Cout);
             constexpr int NCH = 16 / PER;
             int64_t mrow[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) mrow[i] = ((int64_t)t.tb * p.Hin + t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
+            float cbias_[16], cemb_[16];
+            if constexpr (!FOLD) load_cadd2(t, cbias_, cemb_);
             constexpr bool HOIST = false;            // (hoisting all 8 residual chunks ahead of the stores costs 32 VGPRs: spills)
             uint4 rres[HOIST ? 4 : 1][NCH];
             if (HOIST && p.res && full) {
@@ -293,11 +392,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg];
                 if constexpr (!FOLD) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const bool okc = n + k < p.Cout;
-                        if (p.bias && okc) v[k] += p.bias[n + k];
-                        if (p.emb && okc) v[k] += p.emb[(int64_t)t.tb * p.emb_stride + n + k];
-                    }
+                    for (int k = 0; k < 16; ++k) { v[k] += cbias_[k]; v[k] += cemb_[k]; }     // reference order: + bias, then + emb
                 }
                 if (p.res) {
                     if (full) {
@@ -327,7 +422,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
                             const uint4 pk = f32_to_chunk<T>(v + c * PER);
+#ifndef HALO_NO_STORE                                      /* timing diagnostics only (tools/halo_stamps.sh) */
                             *reinterpret_cast<uint4*>(op + c * PER) = pk;
+#endif
                             if constexpr (sizeof(T) == 2) {
                                 if (p.stats) {           // GroupNorm statistics of what was just stored (the rounded values)
                                     const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
@@ -352,15 +449,12 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 }
             }
         }
+        ESTAMP(2);
         if constexpr (sizeof(T) == 2) {
             if (p.stats && n + 16 <= p.Cout) {
                 // reduce over the 16 pixel lanes (fr) of this quarter-wave in a fixed order, then one 16-byte store per
                 // (patch, M-wave, 16-channel slice): stats[b][partial][chunk][{sum, sumsq}]
-                float r4[4] = {gsum[0], gsq[0], gsum[1], gsq[1]};
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) r4[q] += __shfl_xor(r4[q], o, 64);
+                const float r4[4] = {row16_sum(gsum[0]), row16_sum(gsq[0]), row16_sum(gsum[1]), row16_sum(gsq[1])};
                 if (fr == 0) {
                     const int part = ((t.y0 / PATCH) * tiles_x + t.x0 / PATCH) * 4 + wm;
                     float* dst = p.stats + (((int64_t)t.tb * p.stats_P + part) * (p.Cout >> 3) + (n >> 3)) * 2;
@@ -368,7 +462,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 }
             }
         }
+        ESTAMP(3);
         init_acc(cnext);
+        ESTAMP(4);
     };
 
     // ---- prologue (first tile only): halo of block 0, weights of steps 0..2
@@ -476,7 +572,14 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
             hs ^= 1;
         }
+#ifdef HALO_STAMP
+        const int tix_ = (tl - wi) / gx;
+        if (blockIdx.x == 0 && lane == 0 && (tix_ == 1 || tix_ == 2)) g_halo_tile[wave][(tix_ - 1) * 2] = __builtin_amdgcn_s_memtime();
+#endif
         epilogue(cur, nxt);                          // registers -> global, asynchronous stores; no LDS, no barrier
+#ifdef HALO_STAMP
+        if (blockIdx.x == 0 && lane == 0 && (tix_ == 1 || tix_ == 2)) g_halo_tile[wave][(tix_ - 1) * 2 + 1] = __builtin_amdgcn_s_memtime();
+#endif
         if (!has_next) break;
         cur = nxt;
         tl += gx;
@@ -512,6 +615,8 @@ int launch_halo(const KParams& p, hipStream_t stream) {
 extern "C" int nlc_debug_halo_stamps(unsigned long long* out) {
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamps), sizeof(unsigned long long) * 64);
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(g_halo_clock), sizeof(unsigned long long) * 4);
+    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 68, HIP_SYMBOL(g_halo_tile), sizeof(unsigned long long) * 32);
+    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 100, HIP_SYMBOL(g_halo_epi), sizeof(unsigned long long) * 48);
     return rc;
 }
 #endif

@@ -255,7 +255,7 @@ def test_conv_first(dtype):
     if st is not None:
         ch = got.float().cpu().view(2, 32 * 64, 32, 8)
         assert (st.double().sum(1).cpu()[..., 0] - ch.double().sum(dim=(1, 3))).abs().max() < 5e-2
-        assert ((st.double().sum(1).cpu()[..., 1] - (ch.double() ** 2).sum(dim=(1, 3))) / (ch.double() ** 2).sum(dim=(1, 3))).abs().max() < 1e-4
+        assert ((st.double().sum(1).cpu()[..., 1] - (ch.double() ** 2).sum(dim=(1, 3))) / (ch.double() ** 2).sum(dim=(1, 3))).abs().max() < 5e-4
 
 
 def test_row_sumsq_and_quantile():
@@ -299,7 +299,8 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them():
     ref_sum, ref_sq = chunks.sum(dim=(1, 3)), (chunks.double() ** 2).sum(dim=(1, 3))
     got = st.double().sum(dim=1).cpu()
     assert (got[..., 0] - ref_sum.double()).abs().max() < 1e-2 * ref_sum.abs().max().clamp(min=1.0)
-    assert ((got[..., 1] - ref_sq) / ref_sq).abs().max() < 1e-4
+    # (the sums are taken over the f32 values just before their bf16 rounding - zero-mean, 2^-9 relative per element)
+    assert ((got[..., 1] - ref_sq) / ref_sq).abs().max() < 5e-4
     # a second conv makes the skip source of a concatenated GroupNorm input; 384 channels / 32 groups = 12: not a
     # multiple of 8 -> falls back; 256 + 256 = 512 -> group size 16, fused
     y2 = ops.conv2d(_nhwc(x, torch.bfloat16), pw)

@@ -23,7 +23,7 @@ while time.time() < t_end:
     torch.cuda.synchronize()
 torch.cuda.synchronize()
 lib = _ext.load()
-buf = (ctypes.c_ulonglong * 68)()
+buf = (ctypes.c_ulonglong * 148)()
 lib.nlc_debug_halo_stamps.argtypes = [ctypes.c_void_p]
 rc = lib.nlc_debug_halo_stamps(buf)
 st = [[buf[w_ * 8 + q] for q in range(8)] for w_ in range(8)]
@@ -33,6 +33,14 @@ clk = [buf[64 + i] for i in range(4)]
 if clk[3] > clk[1]:
     print(f"in-kernel clock of workgroup 0 over its whole tile loop: {(clk[2] - clk[0]) / (clk[3] - clk[1]) * 100:.0f} MHz "
           f"(ds_memtime / ds_memrealtime x 100 MHz; loop = {(clk[3] - clk[1]) / 100:.1f} us)")
+tt = [[buf[68 + w_ * 4 + q] for q in range(4)] for w_ in range(8)]
+print("tile boundary (cycles): epilogue of tile 1, whole tile 2 = epilogue(1) start -> epilogue(2) start, epilogue of tile 2")
+for w_ in range(8):
+    print(f"  wave {w_}: epilogue1 {tt[w_][1] - tt[w_][0]:6d}   tile2 {tt[w_][2] - tt[w_][0]:7d}   epilogue2 {tt[w_][3] - tt[w_][2]:6d}")
+ep = [[buf[100 + w_ * 6 + q] for q in range(6)] for w_ in range(8)]
+print("inside the epilogue of tile 1 (cycles from its start): cadd loads issued, pixel loop + stores done, stats done, acc re-initialised")
+for w_ in range(8):
+    print(f"  wave {w_}: " + " ".join(f"{ep[w_][q] - ep[w_][0]:7d}" for q in range(1, 5)))
 print("rc", rc, " (s_memtime ticks relative to the earliest wave's step start)")
 print("wave " + " ".join(f"{n:>14s}" for n in names))
 for w_ in range(8):
