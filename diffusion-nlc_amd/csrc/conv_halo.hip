@@ -373,15 +373,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             for (int i = 0; i < 4; ++i) mrow[i] = ((int64_t)t.tb * p.Hin + t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
             float cbias_[16], cemb_[16];
             if constexpr (!FOLD) load_cadd2(t, cbias_, cemb_);
-            constexpr bool HOIST = false;            // (hoisting all 8 residual chunks ahead of the stores costs 32 VGPRs: spills)
-            uint4 rres[HOIST ? 4 : 1][NCH];
-            if (HOIST && p.res && full) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c)
-                        rres[HOIST ? i : 0][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + mrow[i] * p.Cout + n + c * PER);
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t m = mrow[i];
@@ -396,15 +387,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 }
                 if (p.res) {
                     if (full) {
-                        if (!HOIST) {
-#pragma unroll
-                            for (int c = 0; c < NCH; ++c)
-                                rres[0][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + m * p.Cout + n + c * PER);
-                        }
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
                             float rr[PER];
-                            chunk_to_f32<T>(rres[HOIST ? i : 0][c], rr);
+                            chunk_to_f32<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + m * p.Cout + n + c * PER), rr);
 #pragma unroll
                             for (int k = 0; k < PER; ++k) v[c * PER + k] += rr[k];
                         }
