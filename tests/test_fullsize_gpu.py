@@ -55,3 +55,43 @@ def test_adm256_bf16_first_step_tracks_f32(adm256):
     rel_rms = ((out_bf - out_f32).pow(2).mean().sqrt() / out_f32.pow(2).mean().sqrt()).item()
     print(f"ADM-256 forward: bf16 vs f32 L-inf {err:.3e} (scale {scale:.3e}), relative RMS {rel_rms:.3e}")
     assert torch.isfinite(out_bf).all() and err <= 6e-2 * scale and rel_rms <= 2e-2
+
+
+def test_adm256_f32_two_steps_match_the_oracle_at_full_size(adm256):
+    """The headline model itself (ADM-256, 614 M parameters, 256x256) in f32 against the CPU oracle: two full
+    DDIM+NLC timesteps (refine -> encode -> sigma net -> corrected sigma / t -> eps forward -> learned variance,
+    dynamic-threshold clip -> scheduler update) for one image; per-pixel L-inf <= 1e-3 (the north-star tolerance).
+    ~1.5 s of oracle time per timestep on the GPU box's 16 host cores."""
+    import bench
+    from diffusion_nlc_amd.filler import fill_state_dict
+    from diffusion_nlc_amd.script_util import create_sigma_eps_model
+    from oracle import adm
+    from oracle.loop import DiffusionOracle
+    from oracle.sched import get_sampler as oracle_sampler
+    exp = adm256
+    cfg = dict(bench.ADM256)
+    ucfg, scfg, _ = adm.configs_from_factory(**cfg)
+    eps_m, sig_m, _ = create_sigma_eps_model(**cfg)
+    sd_e = fill_state_dict(eps_m.state_dict(), seed=0)                    # the same filler weights the GPU models carry
+    sd_s = fill_state_dict(sig_m.state_dict(), seed=1, overrides=bench.SIGMA_OVERRIDES)
+    del eps_m, sig_m
+    kw = dict(sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="learned", eta=0.0)
+    osched = oracle_sampler("ddim", 1000, 2, **kw)
+    o = DiffusionOracle(lambda x, t: adm.unet(sd_e, ucfg, x, t, "forward"), lambda x, t: adm.unet(sd_e, ucfg, x, t, "encode"),
+                        lambda f: adm.sigma_net(sd_s, scfg, f), osched, (3, 256, 256), learn_epsvar=True, norm_min=0.0,
+                        norm_max=440.0, clip_fn="dynamic")
+    z = torch.randn((1, 3, 256, 256), generator=torch.Generator().manual_seed(99))
+    xT = z / (1 / (osched.sampling_sigmas[0] ** 2 + 1)).sqrt()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    x_cpu = o.denoise_loop((1, 3, 256, 256), style="pred", norm_eps=True, refine_prior_sigma=True, xT=xT, sigma_pred_threshold=960)
+    exp.model.set_compute_dtype(torch.float32)
+    exp.sigma_model.set_compute_dtype(torch.float32)
+    try:
+        x_gpu, _ = exp.denoise_loop(shape=(1, 3, 256, 256), xT=xT, style="pred", norm_eps=True, refine_prior_sigma=True,
+                                    return_log=False, chunk_size=1, sigma_pred_threshold=960)
+    finally:
+        exp.model.set_compute_dtype(torch.bfloat16)
+        exp.sigma_model.set_compute_dtype(torch.bfloat16)
+    err = (x_gpu.double() - x_cpu.double()).abs().max().item()
+    print(f"ADM-256 f32, 2 DDIM+NLC timesteps, 1 image: HIP vs CPU oracle L-inf = {err:.3e}")
+    assert err <= 1e-3, err
