@@ -95,3 +95,105 @@ def test_adm256_f32_two_steps_match_the_oracle_at_full_size(adm256):
     err = (x_gpu.double() - x_cpu.double()).abs().max().item()
     print(f"ADM-256 f32, 2 DDIM+NLC timesteps, 1 image: HIP vs CPU oracle L-inf = {err:.3e}")
     assert err <= 1e-3, err
+
+
+def test_celebahq256_inpainting_f32_matches_the_oracle_at_full_size():
+    """BASELINE config 4 at full model size: the DDPM 'simple' UNet (ch 128, mult 1-1-2-2-4-4, 113.7 M + 15.5 M
+    parameters) at 256x256, seeded random 50 % inpainting mask, three DDIM+NLC timesteps with the projection fused into the
+    scheduler kernel - f32 HIP path vs the CPU oracle with the reference-shaped affine projection."""
+    import argparse
+    from diffusion_nlc_amd import script_util
+    from diffusion_nlc_amd.constraint_functions import Constraint_Function, Inpainting
+    from diffusion_nlc_amd.experiments import ImageExperiment
+    from diffusion_nlc_amd.filler import fill_state_dict
+    from diffusion_nlc_amd.schedulers import get_sampler
+    from oracle import simple
+    from oracle.loop import DiffusionOracle
+    from oracle.sched import get_sampler as oracle_sampler
+    ns = argparse.Namespace
+    mc = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[16], dropout=0.0, in_channels=3,
+              resamp_with_conv=True, feat_layer=1, type="simple", sigma_block=2, sigma_dropout=0.0)
+    config = ns(model=ns(**mc), data=ns(image_size=256), diffusion=ns(num_diffusion_timesteps=1000))
+    eps, sig, _ = script_util.create_simple_sigma_eps_model(config)
+    sd_e = fill_state_dict(eps.state_dict(), seed=0)
+    sd_s = fill_state_dict(sig.state_dict(), seed=1, overrides={"final_mlp.weight": 0.1, "final_mlp.bias": 0.5})
+    eps.load_state_dict(sd_e); sig.load_state_dict(sd_s)
+    eps.to("cuda:0"); sig.to("cuda:0")
+    res, B, steps = 256, 1, 3
+    g = torch.Generator().manual_seed(11)
+    missing_r = torch.randperm(res * res, generator=g)[: res * res // 2].long() * 3
+    missing = torch.cat([missing_r, missing_r + 1, missing_r + 2], dim=0)
+    x_gt = torch.rand(B, 3, res, res, generator=g) * 2 - 1
+    kw = dict(sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    # ---- oracle (CPU): mask semantics of functions/svd_operators.py:324-359 restated on flat (c,h,w)-interleaved indices
+    keep = torch.ones(3 * res * res, dtype=torch.bool); keep[missing] = False
+    def to_flat(x): return x.reshape(B, 3, -1).permute(0, 2, 1).reshape(B, -1)          # pixel-major, channel-minor
+    def from_flat(v): return v.reshape(B, -1, 3).permute(0, 2, 1).reshape(B, 3, res, res)
+    y_flat = to_flat(x_gt)[:, keep]
+    def constrain(x0):
+        f = to_flat(x0).clone(); f[:, keep] = y_flat
+        return from_flat(f)
+    cfg = simple.SimpleConfig(ch=128, out_ch=3, ch_mult=(1, 1, 2, 2, 4, 4), num_res_blocks=2, attn_resolutions=(16,), in_channels=3,
+                              resolution=256, resamp_with_conv=True, feat_layer=1, sigma_block=2)
+    _, dim = simple.sigma_dims(cfg)
+    osched = oracle_sampler("ddim", 1000, steps, **kw)
+    o = DiffusionOracle(lambda x, t: simple.unet(sd_e, cfg, x, t, "forward"), lambda x, t: simple.unet(sd_e, cfg, x, t, "encode"),
+                        lambda f: simple.sigma_net(sd_s, dim, cfg.sigma_block, f), osched, (3, res, res), learn_epsvar=False,
+                        norm_min=0.0, norm_max=397.0, clip_fn="clamp")
+    z = torch.randn((B, 3, res, res), generator=torch.Generator().manual_seed(5))
+    xT = z / (1 / (osched.sampling_sigmas[0] ** 2 + 1)).sqrt()
+    x_cpu = o.denoise_loop((B, 3, res, res), style="pred", constrain_fn=constrain, norm_eps=True, refine_prior_sigma=True, xT=xT,
+                           sigma_pred_threshold=960)
+    # ---- HIP path
+    s = get_sampler("ddim", 1000, steps, **kw)
+    s.to("cuda:0")
+    exp = ImageExperiment(eps, s, batch_size=B, data_shape=(3, res, res), seed=5, device="cuda:0")
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 397.0)
+    exp.set_clip_fn("clamp")
+    op = Inpainting(3, res, missing, "cuda:0")
+    cf = Constraint_Function("inpainting_random", op, channels=3, image_size=res)
+    y = op.A(x_gt)
+    x_gpu, _ = exp.denoise_loop(shape=(B, 3, res, res), xT=xT, style="pred", constrain_fn=cf.bind(y, (B, 3, res, res)), norm_eps=True,
+                                refine_prior_sigma=True, return_log=False, chunk_size=1, sigma_pred_threshold=960)
+    err = (x_gpu.double() - x_cpu.double()).abs().max().item()
+    known = (x_gpu - x_gt).abs()[:, keep.view(res * res, 3).t().reshape(3, res, res)].max().item()
+    print(f"CelebA-HQ-256 simple UNet f32, 3 constrained DDIM+NLC timesteps: HIP vs CPU oracle L-inf = {err:.3e}; known pixels off by {known:.1e}")
+    assert err <= 1e-3 and known == 0.0
+
+
+def test_edm_cifar10_f32_matches_the_oracle_at_full_size():
+    """BASELINE config 3 at full model size: SongUNet (128 channels, mult 2-2-2, 4 blocks, 55.7 M + 3.9 M parameters),
+    32x32, Heun + NLC 'pred_partial,pred', 6 sigma steps, float64 state: HIP vs the CPU oracle."""
+    from diffusion_nlc_amd import script_util
+    from diffusion_nlc_amd.experiments import EDMImageExperiment
+    from diffusion_nlc_amd.filler import fill_state_dict
+    from oracle import edm
+    from oracle.loop import EdmOracle
+    mc = dict(img_resolution=32, in_channels=3, out_channels=3, augment_dim=9, model_channels=128, channel_mult=[2, 2, 2],
+              num_blocks=4, attn_resolutions=[16], dropout=0.0, sigma_block=2, sigma_dropout=0.0)
+    eps, sig, _ = script_util.create_edm_sigma_eps_model(**mc)
+    tmpl = eps.state_dict()
+    for k in tmpl:
+        if k.endswith("resample_filter"):
+            tmpl[k] = torch.ones_like(tmpl[k]) / 4.0
+    sd_e = fill_state_dict(tmpl, seed=0)
+    sd_s = fill_state_dict(sig.state_dict(), seed=1, overrides={"final_mlp.weight": 0.1, "final_mlp.bias": 0.5})
+    eps.load_state_dict(sd_e); sig.load_state_dict(sd_s)
+    eps.to("cuda:0"); sig.to("cuda:0")
+    B, steps = 4, 6
+    cfg = edm.EdmConfig(img_resolution=32, in_channels=3, out_channels=3, augment_dim=9, model_channels=128, channel_mult=(2, 2, 2),
+                        num_blocks=4, attn_resolutions=(16,), sigma_block=2)
+    _, dim = edm.sigma_dims(cfg)
+    o = EdmOracle(lambda x, t: edm.unet(sd_e, cfg, x, t, "forward"), lambda x, t: edm.unet(sd_e, cfg, x, t, "encode"),
+                  lambda f: edm.sigma_net(sd_s, dim, cfg.sigma_block, f), (3, 32, 32), num_timesteps=steps, norm_min=0.0, norm_max=54.63)
+    lat = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(77))
+    x_cpu = o.edm_sampler(lat, style="pred_partial,pred", norm_eps="000", eps_ratio=0.5, eps_scale=1.0, use_second_order=True)
+    exp = EDMImageExperiment(eps, None, batch_size=B, data_shape=(3, 32, 32), seed=0, device="cuda:0", num_timesteps=steps)
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 54.63)
+    x_gpu = exp.edm_sampler(shape=(B, 3, 32, 32), latents=lat, style="pred_partial,pred", norm_eps="000", eps_ratio=0.5, eps_scale=1.0,
+                            use_second_order=True)
+    err = (x_gpu.cpu().double() - x_cpu.double()).abs().max().item()
+    print(f"EDM CIFAR-10 SongUNet f32 / f64 state, 6-step Heun+NLC: HIP vs CPU oracle L-inf = {err:.3e}")
+    assert x_gpu.dtype == torch.float64 and err <= 1e-3
