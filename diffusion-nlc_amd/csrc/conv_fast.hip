@@ -414,6 +414,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
     if (p.out_mode == NLC_OUT_NHWC) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) ElemTraits<T>::store(reinterpret_cast<T*>(p.out) + off + k, r[k]);
+        if constexpr (sizeof(T) == 2) {
+            if (p.stats) {
+                // GroupNorm statistics ride along here too (the 16x16 / 8x8 levels): two neighbouring threads hold one
+                // 8-channel chunk of one pixel; one partial per pixel (stats_P = Hout * Wout), dispatch: Cout % 8 == 0
+                float s1 = (r[0] + r[1]) + (r[2] + r[3]);
+                float s2 = fmaf(r[0], r[0], fmaf(r[1], r[1], fmaf(r[2], r[2], r[3] * r[3])));
+                s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, false));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0xB1, 0xf, 0xf, false));
+                if (((n >> 2) & 1) == 0) {
+                    const int64_t pix = m - (int64_t)b * HWo;
+                    float* dst = p.stats + (((int64_t)b * p.stats_P + pix) * (p.Cout >> 3) + (n >> 3)) * 2;
+                    *reinterpret_cast<float2*>(dst) = float2{s1, s2};
+                }
+            }
+        }
     } else {
         const int64_t rem = m - (int64_t)b * HWo;
 #pragma unroll
@@ -467,13 +482,13 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     return s < 2 ? 1 : s;
 }
 
-// GroupNorm statistics ride along on the fast path when every 128-pixel tile lies inside one image, the N-tiles are
-// whole, the output is bf16 NHWC and K is not split (the split-K reduce kernel has no statistics epilogue)
+// GroupNorm statistics ride along on the fast path when the N-tiles are whole and the output is bf16 NHWC: from the conv
+// epilogue if every 128-pixel tile lies inside one image, from the split-K reduce kernel when K is split
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
     if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0 || !fast_shape(p)) return 0;
     const int HWo = p.Hout * p.Wout;
+    if (nlc_conv_fast_ksplit(p, dtype) > 1) return HWo;          // split-K: the reduce kernel emits one partial per pixel
     if (HWo % BM) return 0;
-    if (nlc_conv_fast_ksplit(p, dtype) > 1) return 0;
     return (HWo / BM) * 2;
 }
 

@@ -332,6 +332,10 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
                 p.ksplit = ks; p.partial = (float*)d->workspace;
             }
         }
+        // the statistics layout was sized for the kernel that nlc_conv2d_stats_partials predicted (split-K reduce: one
+        // partial per pixel; otherwise two per 128-pixel tile): the workspace decides which one actually runs
+        NLC_REQUIRE(!p.stats || (nlc_conv_fast_ksplit(p, dtype) > 1) == (p.ksplit > 1),
+                    "nlc_conv2d: stats_out on a split-K shape needs the workspace of nlc_conv2d_workspace_bytes");
         rc = nlc_conv_fast_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         p.ksplit = 1; p.partial = nullptr;

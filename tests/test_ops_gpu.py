@@ -311,6 +311,16 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them():
         plain = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=True, x1=y2)
     finally:
         ops.FUSED_GN_STATS = True
+    # split-K shape (8x8 level; not halo-eligible): the statistics come from the reduce kernel, one partial per pixel
+    xs = torch.randn(2, 512, 8, 8, generator=g)
+    ws = torch.randn(256, 512, 3, 3, generator=g) / math.sqrt(512 * 9)
+    ys = ops.conv2d(_nhwc(xs, torch.bfloat16), ops.pack_conv(ws, b, torch.bfloat16, _dev()))
+    sts = getattr(ys, "_nlc_stats", None)
+    assert sts is not None and sts.shape == (2, 64, 32, 2)
+    chs = ys.float().cpu().view(2, 64, 32, 8)
+    ref_s = chs.double().sum(dim=(1, 3))              # 512 stored values per chunk; the kernel summed them before rounding
+    assert (sts.double().sum(1).cpu()[..., 0] - ref_s).abs().max() < 2e-3 * ref_s.abs().max()
+    assert ((sts.double().sum(1).cpu()[..., 1] - (chs.double() ** 2).sum(dim=(1, 3))) / (chs.double() ** 2).sum(dim=(1, 3))).abs().max() < 2e-3
     cat = torch.cat([yf, y2.float().cpu()], dim=-1).permute(0, 3, 1, 2)
     ref = F.silu(F.group_norm(cat, 32, gamma.cpu(), beta.cpu(), eps=1e-5)).permute(0, 2, 3, 1)
     scale = ref.abs().max().item()
