@@ -121,7 +121,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // ---- persistent tile schedule: XCD x (= workgroup id & 7, the dispatcher's round-robin) owns a contiguous
     //      chunk of the tile list (N-tile fastest, so neighbours in time share the halo and the weights in that
     //      XCD's L2); the workgroups of an XCD walk their chunk with stride (workgroups per XCD).
-    const int tiles_x = p.Win / PATCH, tiles_y = p.Hin / PATCH;
+    const int tiles_x = p.Wout / PATCH, tiles_y = p.Hout / PATCH;          // (Hout, Wout) = 2 x (Hin, Win) with the fused nearest-2x upsample
     const int nblk = p.B * tiles_y * tiles_x * p.NT;
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
@@ -170,8 +170,12 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             const int R = (wave + 8 * j) * 8 + lrow;
             const int hy = R / HALO, hx = R - hy * HALO;
             const int iy = t.y0 + hy - 1, ix = t.x0 + hx - 1;
-            const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-            const int64_t pixel = ((int64_t)t.tb * p.Hin + iy) * p.Win + ix;
+            // (iy, ix) are coordinates in the conv's (possibly virtual, nearest-2x upsampled) input = output grid; with the
+            // upsample fused the halo row is fetched from source pixel (iy >> 1, ix >> 1) - the LDS image holds the
+            // upsampled patch, so the k-loop does not know about it (src/unet_adm.py:107-109)
+            const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout;
+            const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
+            const int64_t pixel = ((int64_t)t.tb * p.Hin + sy) * p.Win + sx;
             haddr[j] = ok ? src + (pixel * C + hchunk * PER) * ES : zero;
         }
     };
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     //      column fr, the 16 consecutive output channels n0 + wn*64 + fq*16 + [0, 16)  (acc[i][j][reg] -> j*4 + reg).
     //      bias + embedding are folded into the accumulators' INITIAL value (loaded for the next tile while the
     //      current one is being stored), the residual chunks are all requested before the first one is used.
-    const int HWo = p.Hin * p.Win;
+    const int HWo = p.Hout * p.Wout;
     const bool vec_ok = (p.Cout % PER) == 0;
     // bf16: bias + embedding are folded into the accumulators' initial value.  f32 (the parity path) keeps the
     // reference's order instead - conv sum, then + bias, then + embedding, then + residual - so that it rounds like
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 const int act = p.act;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int64_t m = ((int64_t)t.tb * p.Hin + t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
+                    const int64_t m = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4 + i) * p.Wout + t.x0 + fr;
                     float v[16];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             constexpr int NCH = 16 / PER;
             int64_t mrow[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mrow[i] = ((int64_t)t.tb * p.Hin + t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
+            for (int i = 0; i < 4; ++i) mrow[i] = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4 + i) * p.Wout + t.x0 + fr;
             float cbias_[16], cemb_[16];
             if constexpr (!FOLD) load_cadd2(t, cbias_, cemb_);
 #pragma unroll
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                         for (int k = 0; k < 16; ++k) if (n + k < p.Cout) ElemTraits<T>::store(op + k, v[k]);
                     }
                 } else {
-                    const int64_t rem = (int64_t)(t.y0 + wm * 4 + i) * p.Win + t.x0 + fr;
+                    const int64_t rem = (int64_t)(t.y0 + wm * 4 + i) * p.Wout + t.x0 + fr;
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                         if (n + k < p.Cout) reinterpret_cast<float*>(p.out)[((int64_t)t.tb * p.Cout + n + k) * HWo + rem] = v[k];
@@ -587,7 +591,7 @@ int launch_halo(const KParams& p, hipStream_t stream) {
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
         attr_set = true;
     }
-    const int nblk = p.B * (p.Hin / PATCH) * (p.Win / PATCH) * p.NT;
+    const int nblk = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT;
     const int grid = nblk < ncu ? nblk : ncu;        // one persistent workgroup per CU (154 KiB of LDS each)
     hipLaunchKernelGGL((conv_halo_kernel<T>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
     hipError_t e = hipGetLastError();
@@ -612,12 +616,13 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     const bool forced = force && force[0] == '1';
     if (forced_out) *forced_out = forced;
     if (force && force[0] == '0') return false;
-    if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1 && !p.ups)) return false;
-    if (p.Hin % PATCH || p.Win % PATCH || p.Hout != p.Hin || p.Wout != p.Win) return false;
+    if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1)) return false;
+    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
+    if (p.Hout % PATCH || p.Wout % PATCH || p.Hout != HL || p.Wout != WL) return false;
     const int kbe = dtype == NLC_BF16 ? MmaH<bf16_raw>::KBE : MmaH<float>::KBE;
     if (p.C0 % kbe || p.C1 % kbe || p.Cin_pad / kbe > 128) return false;
-    if ((int64_t)p.B * p.Hin * p.Win >= (1ll << 31)) return false;
-    const int blocks = p.B * (p.Hin / PATCH) * (p.Win / PATCH) * p.NT;
+    if ((int64_t)p.B * p.Hout * p.Wout >= (1ll << 31)) return false;
+    const int blocks = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT;
     return forced || blocks >= 256;
 }
 
@@ -625,10 +630,10 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
     if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
     if (!halo_eligible(p, dtype, nullptr)) return 0;
-    return (p.Hin / PATCH) * (p.Win / PATCH) * 4;
+    return (p.Hout / PATCH) * (p.Wout / PATCH) * 4;
 }
 
-// 3x3 / stride 1 / pad 1 / no upsample, H and W multiples of 16, enough tiles to fill the chip.
+// 3x3 / stride 1 / pad 1 (optionally on the nearest-2x upsampled input), output H and W multiples of 16, enough tiles to fill the chip.
 // NLC_CONV_HALO=0 disables, =1 forces (for eligible shapes) regardless of the tile count.
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!halo_eligible(p, dtype, nullptr)) return NLC_EUNSUPPORTED;

@@ -62,6 +62,7 @@ CONV_CASES = [
     dict(B=1, Cin=128, H=48, W=32, Cout=256, k=3, bias=False),
     dict(B=2, Cin=192, H=16, W=32, Cout=200, k=3, split=64, emb=True, res=True, scale=math.sqrt(0.5)),   # concat at a block edge
     dict(B=2, Cin=64, H=32, W=32, Cout=6, k=3, act="silu", nchw=True),
+    dict(B=2, Cin=128, H=16, W=24, Cout=128, k=3, ups=True, emb=True, res=True),        # fused nearest-2x upsample in the halo kernel
     # > 256 tiles: every persistent workgroup walks 2 tiles (cross-tile DMA streams, accumulator re-init, both N-tiles)
     dict(B=1, Cin=64, H=256, W=256, Cout=256, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
     dict(B=2, Cin=128, H=256, W=128, Cout=256, k=3, split=64, act="silu"),

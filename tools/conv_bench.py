@@ -13,7 +13,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from diffusion_nlc_amd import ops  # noqa: E402
 
-SHAPES = [  # (H, Cin, Cout, k, note)
+SHAPES = [  # (H, Cin, Cout, k, note); a trailing "ups" in the note = fused nearest-2x upsample (H is the INPUT size)
     (256, 256, 256, 3, "256->256 @256^2 (31% of FLOPs)"),
     (256, 512, 256, 3, "512->256 @256^2"),
     (128, 256, 256, 3, "256->256 @128^2"),
@@ -23,6 +23,8 @@ SHAPES = [  # (H, Cin, Cout, k, note)
     (8, 1024, 1024, 3, "1024->1024 @8^2"),
     (256, 768, 256, 1, "1x1 768->256 @256^2"),
     (32, 512, 1536, 1, "qkv 512->1536 @32^2"),
+    (128, 256, 256, 3, "256->256 @128^2->256^2 ups"),
+    (64, 512, 512, 3, "512->512 @64^2->128^2 ups"),
 ]
 
 
@@ -42,17 +44,18 @@ def main():
         x = torch.randn(args.batch, H, H, cin, device=dev).to(dt)
         w = torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)
         pw = ops.pack_conv(w, torch.zeros(cout), dt, dev)
+        ups = note.endswith("ups")
         for _ in range(3):
-            ops.conv2d(x, pw)
+            ops.conv2d(x, pw, upsample2x=ups)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            ops.conv2d(x, pw)
+            ops.conv2d(x, pw, upsample2x=ups)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
-        fl = 2.0 * args.batch * H * H * cout * cin * k * k
+        fl = 2.0 * args.batch * H * H * cout * cin * k * k * (4 if ups else 1)
         print(f"{note:32s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
 
 
