@@ -20,6 +20,22 @@ namespace {
 constexpr int NTHREADS = 256;
 constexpr int QB = 64;      // query rows per workgroup
 
+// reductions over the 16 lanes of a DPP row (= the 16 score columns a lane group holds), result in every lane: VALU
+// only (quad_perm xor 1, xor 2, row_half_mirror, row_mirror).  A __shfl_xor is a ds_bpermute (~100 cycles); the 16 of
+// them per key tile cost several times the tile's 16 MFMAs.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float x) {
+    x = fmaxf(x, dpp_mov<0xB1>(x)); x = fmaxf(x, dpp_mov<0x4E>(x));
+    x = fmaxf(x, dpp_mov<0x141>(x)); x = fmaxf(x, dpp_mov<0x140>(x));
+    return x;
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_mov<0xB1>(x); x += dpp_mov<0x4E>(x); x += dpp_mov<0x141>(x); x += dpp_mov<0x140>(x);
+    return x;
+}
+
 template <int RB> __device__ __forceinline__ int swz_chunk(int row, int c) {
     if constexpr (RB >= 256) return c ^ (row & 15);
     else if constexpr (RB == 128) return c ^ ((row >> 1) & 7);
@@ -110,6 +126,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
             *reinterpret_cast<uint4*>(Vs + lds_addr<C::RBK>(row, c)) = vv;
         }
         __syncthreads();
+        // (register double-buffering of the K / V tiles was measured slower, 125 vs 112 us at T = 1024: several
+        //  workgroups per CU already hide the load latency and the extra 16 VGPRs cost occupancy)
 
         // ---- S = Q K^T  (16 x KVT per wave)
         f32x4_t s[C::NNT];
@@ -138,10 +156,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) tmax[r] = fmaxf(tmax[r], __shfl_xor(tmax[r], off, 64));
-        }
+        for (int r = 0; r < 4; ++r) tmax[r] = row16_max(tmax[r]);
         float alpha[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -209,10 +224,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
 
     // ---- finish: reduce row sums across the 16 lanes of each group, normalise, store
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) lrow[r] += __shfl_xor(lrow[r], off, 64);
-    }
+    for (int r = 0; r < 4; ++r) lrow[r] = row16_sum(lrow[r]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = q0 + wave * 16 + fq * 4 + r;
