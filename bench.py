@@ -198,10 +198,19 @@ def main():
                     tj = json.load(f)
                 dom = [(e0.elapsed_time(e1), fl) for e0, e1, fl, d, shp in prof
                        if d == dtype and shp[:4] == (args.batch * res * res, 256, 9, 256) and shp[5] == 0]
-                line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
-                line["roofline"]["traffic_of"] = {"kernel": tj["kernel"], "algorithmic_bytes": tj["algorithmic_bytes_per_launch"],
-                                                  "launch_us": 1e3 * sum(t for t, _ in dom) / max(len(dom), 1),
-                                                  "tflops": sum(fl for _, fl in dom) / max(sum(t for t, _ in dom), 1e-9) / 1e9}
+                dominant = {"kernel": tj["kernel"], "traffic": tj["traffic_bytes_per_launch"],
+                            "algorithmic_bytes": tj["algorithmic_bytes_per_launch"],
+                            "launch_us": 1e3 * sum(t for t, _ in dom) / max(len(dom), 1),
+                            "tflops": sum(fl for _, fl in dom) / max(sum(t for t, _ in dom), 1e-9) / 1e9}
+                # per-launch average over ALL nlc_conv2d launches of a bench step (same population as `achieved`), from
+                # PMC passes over two NLC timesteps of this workload: profiles/r01f_pmc_traffic_all.json
+                apath = os.path.join(os.path.dirname(tpath), "r01f_pmc_traffic_all.json")
+                if os.path.exists(apath):
+                    with open(apath) as f:
+                        line["roofline"]["traffic"] = json.load(f)["conv2d_bytes_per_launch"]
+                else:
+                    line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+                line["roofline"]["traffic_of_dominant_launch"] = dominant
             if os.environ.get("NLC_BENCH_SHAPES"):
                 agg = {}
                 for e0, e1, f, d, shp in prof:
