@@ -2,28 +2,34 @@
 """Headline benchmark: images/sec, 256x256 50-step DDIM + NLC on the ADM-256 UNet (BASELINE.json
 configs[1]: batch 16 per GPU, bf16 operands / f32 accumulate, synthetic inputs and filler weights).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        # N > 1: starts its own N ranks (see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W           # or under a launcher that already set RANK / WORLD_SIZE
 
-One "step" = one full 50-timestep DDIM+NLC sampling pass of one batch (16 images) per GPU:
+One "step" = one full sampling pass of one batch per GPU (ADM-256: 50 DDIM+NLC timesteps of 16 images):
 per timestep  UNet.encode -> sigma net -> UNet.forward -> scheduler update.  Every rank samples its
-own batches (weak scaling, independent samples); the single collective is one RCCL
-all-gather of the finished samples inside the timed region.  Rank 0 prints ONE JSON line.
+own batches (weak scaling, independent samples); the finished samples stay in HBM and the
+single collective is one RCCL all-gather of them inside the timed region.  Rank 0 prints ONE JSON line.
 
-Extra objects on that line:
-  roofline     the dominant kernel (conv_igemm_kernel, bf16 MFMA): algorithmic direct-conv FLOPs of its
-               launches / their summed duration, measured with HIP events on the launch stream during
-               the timed region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+The timed region runs the product path with no instrumentation.  After it, rank 0 runs ONE more step with
+HIP events around every convolution launch (on the launch stream) for the `roofline` object:
+  roofline     all nlc_conv2d launches of a step: algorithmic direct-conv FLOPs / their summed duration;
+               peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).  `traffic` comes from separate rocprofv3
+               --pmc passes of the same build (profiles/, tagged with the hash of the kernel sources).
   cpu_baseline the CPU oracle (oracle/, a port of the reference's PyTorch-CPU path) timed on the host
-               cores of this box on ONE ADM-256 DDIM+NLC timestep at B=1, extrapolated x50.
+               cores of this box on a bounded sample of the same workload, extrapolated.
+
+Other workloads (BASELINE.json configs[2], configs[3]; not the headline metric):  --config edm32 | celebahq256.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -36,12 +42,21 @@ sys.path.insert(0, str(ROOT))
 ADM256 = dict(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", learn_sigma=True,
               attention_resolutions="32,16,8", num_heads=4, num_head_channels=64, use_scale_shift_norm=True,
               resblock_updown=True, use_new_attention_order=False, sigma_block=2)
-# per image, one DDIM+NLC timestep: forward + encode + sigma net (BASELINE.md §2, 2*MAC of conv/linear/bmm)
-GF_PER_IMAGE_STEP = 2239.67 + 580.29 + 3.95
+EDM32 = dict(img_resolution=32, in_channels=3, out_channels=3, augment_dim=9, model_channels=128, channel_mult=[2, 2, 2],
+             num_blocks=4, attn_resolutions=[16], dropout=0.0, sigma_block=2, sigma_dropout=0.0)
+CELEBAHQ = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, attn_resolutions=[16], dropout=0.0, in_channels=3,
+                resamp_with_conv=True, feat_layer=1, type="simple", sigma_block=2, sigma_dropout=0.0)
+# per image, one network evaluation with NLC: forward + encode + sigma net (BASELINE.md §2, 2*MAC of conv/linear/bmm)
+GF_PER_IMAGE_STEP = 2239.67 + 580.29 + 3.95          # ADM-256
+GF_EDM_EVAL = 42.38 + 13.76 + 0.25                    # EDM CIFAR-32 SongUNet
+GF_CELEBA_STEP = 497.03 + 135.15 + 0.99               # CelebA-HQ-256 simple UNet
 PEAK_BF16_DENSE_TFLOPS = 2500.0
 SIGMA_OVERRIDES = {"final_mlp.weight": 0.1, "final_mlp.bias": 0.5}
 
 
+# ------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------
 def build_models(cfg, device, dtype):
     from diffusion_nlc_amd import script_util
     from diffusion_nlc_amd.filler import fill_state_dict
@@ -67,41 +82,270 @@ def make_experiment(cfg, device, dtype, batch, timesteps):
     return exp
 
 
-def cpu_baseline(cfg, max_seconds=240.0):
-    """Time the oracle (CPU port) on one DDIM+NLC timestep of ADM-256 at B=1."""
-    from diffusion_nlc_amd.filler import fill_state_dict
-    from diffusion_nlc_amd.script_util import create_sigma_eps_model
-    from oracle import adm
-    from oracle.loop import DiffusionOracle
-    from oracle.sched import get_sampler
-    # the GPU box shares its host: a 1-GPU slot owns 16 cores (os.cpu_count() reports the whole machine)
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    torch.set_num_threads(cores)
-    ucfg, scfg, _ = adm.configs_from_factory(**cfg)
-    eps_m, sig_m, _ = create_sigma_eps_model(**cfg)
-    sd_e = fill_state_dict(eps_m.state_dict(), seed=0)
-    sd_s = fill_state_dict(sig_m.state_dict(), seed=1, overrides=SIGMA_OVERRIDES)
-    s = get_sampler("ddim", 1000, 50, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="learned", eta=0.0)
-    res = cfg["image_size"]
-    o = DiffusionOracle(lambda x, t: adm.unet(sd_e, ucfg, x, t, "forward"), lambda x, t: adm.unet(sd_e, ucfg, x, t, "encode"),
-                        lambda f: adm.sigma_net(sd_s, scfg, f), s, (3, res, res), learn_epsvar=True, norm_min=0.0,
-                        norm_max=440.0 * res / 256, clip_fn="dynamic")
-    z = torch.randn((1, 3, res, res), generator=torch.Generator().manual_seed(1234))
-    xt = z / (1 / (s.sampling_sigmas[0] ** 2 + 1)).sqrt()
-    def one_timestep(x, ind):
-        eps, lv, st, sp = o.get_denoise_vector(x, s.timesteps[ind], s.sampling_sigmas[ind], s.sampling_sigmas[ind + 1], "pred", True, True)
-        x0 = o.clip(s.pred_xstart(x, eps, st))
-        return s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=x, log_variance=lv)
+class AdmWorkload:
+    """BASELINE.json configs[1]: ADM UNet 256x256, 50-step DDIM+NLC, batch 16 per GPU (the headline metric)."""
+    name = "adm256"
 
-    # bounded sample: keep stepping the real trajectory until ~15 s of CPU work (at most 20 of the 50 timesteps)
-    n, t0 = 0, time.perf_counter()
-    with torch.no_grad():
-        while n < 20 and (n == 0 or time.perf_counter() - t0 < 15.0):
-            xt = one_timestep(xt, n)
+    def __init__(self, args, device, dtype):
+        self.cfg = dict(ADM256)
+        if args.tiny:
+            self.cfg.update(image_size=64, num_channels=64, channel_mult="1,2,2,4", attention_resolutions="16,8", num_head_channels=32)
+        self.res, self.batch, self.timesteps, self.device = self.cfg["image_size"], args.batch or 16, args.timesteps or 50, device
+        self.shape = (self.batch, 3, self.res, self.res)
+        self.exp = None if args.dry_run else make_experiment(self.cfg, device, dtype, self.batch, self.timesteps)
+        self.headline = self.res == 256 and self.timesteps == 50
+        self.metric = ("images/sec whole-node, 256x256 50-step DDIM+NLC" if self.headline
+                       else f"images/sec, {self.res}x{self.res} {self.timesteps}-step DDIM+NLC (debug configuration)")
+        self.workload = (f"ADM UNet {self.res}x{self.res} (src/unet_adm.py), {self.timesteps}-step DDIM+NLC, batch {self.batch} per GPU, "
+                         f"{args.dtype}, dynamic-threshold clip, learned variance, filler weights")
+        self.gflop_per_image = self.timesteps * GF_PER_IMAGE_STEP if self.res == 256 else None
+
+    def inputs(self, n_total, world, rank):
+        from diffusion_nlc_amd import shard
+        zs = shard.draw_initial_noise(self.shape, n_total, 1234, world, rank)          # host, reference draw order
+        if self.exp is None:
+            return [z.to(self.device) for z in zs]
+        sigma0 = self.exp.scheduler.sampling_sigmas[0]
+        return [(z / (1 / (sigma0 ** 2 + 1)).sqrt()).to(self.device) for z in zs]       # resident in HBM before timing
+
+    def run(self, xT):
+        x, _ = self.exp.denoise_loop(shape=self.shape, xT=xT, style="pred", norm_eps=True, refine_prior_sigma=True,
+                                     return_log=False, chunk_size=1, sigma_pred_threshold=960, return_on_device=True)
+        return x
+
+    def cpu_baseline(self):
+        """Time the oracle (CPU port) on DDIM+NLC timesteps of ADM-256 at B=1."""
+        from diffusion_nlc_amd.filler import fill_state_dict
+        from diffusion_nlc_amd.script_util import create_sigma_eps_model
+        from oracle import adm
+        from oracle.loop import DiffusionOracle
+        from oracle.sched import get_sampler
+        cfg = self.cfg
+        cores = _host_cores()
+        torch.set_num_threads(cores)
+        ucfg, scfg, _ = adm.configs_from_factory(**cfg)
+        eps_m, sig_m, _ = create_sigma_eps_model(**cfg)
+        sd_e = fill_state_dict(eps_m.state_dict(), seed=0)
+        sd_s = fill_state_dict(sig_m.state_dict(), seed=1, overrides=SIGMA_OVERRIDES)
+        s = get_sampler("ddim", 1000, 50, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="learned", eta=0.0)
+        res = cfg["image_size"]
+        o = DiffusionOracle(lambda x, t: adm.unet(sd_e, ucfg, x, t, "forward"), lambda x, t: adm.unet(sd_e, ucfg, x, t, "encode"),
+                            lambda f: adm.sigma_net(sd_s, scfg, f), s, (3, res, res), learn_epsvar=True, norm_min=0.0,
+                            norm_max=440.0 * res / 256, clip_fn="dynamic")
+        z = torch.randn((1, 3, res, res), generator=torch.Generator().manual_seed(1234))
+        xt = z / (1 / (s.sampling_sigmas[0] ** 2 + 1)).sqrt()
+
+        def one_timestep(x, ind):
+            eps, lv, st, sp = o.get_denoise_vector(x, s.timesteps[ind], s.sampling_sigmas[ind], s.sampling_sigmas[ind + 1], "pred", True, True)
+            x0 = o.clip(s.pred_xstart(x, eps, st))
+            return s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=x, log_variance=lv)
+
+        # bounded sample: keep stepping the real trajectory until ~15 s of CPU work (at most 20 of the 50 timesteps)
+        n, t0 = 0, time.perf_counter()
+        with torch.no_grad():
+            while n < 20 and (n == 0 or time.perf_counter() - t0 < 15.0):
+                xt = one_timestep(xt, n)
+                n += 1
+        dt = (time.perf_counter() - t0) / n
+        return {"value": 1.0 / (50.0 * dt), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} DDIM+NLC timestep(s) of ADM-{res} at B=1 in f32 on the host ({dt:.2f} s each), extrapolated to 50 timesteps"}
+
+
+class EdmWorkload:
+    """BASELINE.json configs[2]: EDM SongUNet 32x32 (CIFAR-10 architecture), Heun sampler + NLC, 18 sigma steps
+    (35 network evaluations with NLC), float64 state, batch 200 (the reference CLI default, edm_image_sample.py:35)."""
+    name = "edm32"
+
+    def __init__(self, args, device, dtype):
+        from diffusion_nlc_amd import script_util
+        from diffusion_nlc_amd.experiments import EDMImageExperiment
+        from diffusion_nlc_amd.filler import fill_state_dict
+        self.batch, self.steps, self.device = args.batch or 200, args.timesteps or 18, device
+        self.shape = (self.batch, 3, 32, 32)
+        self.exp = None
+        if not args.dry_run:
+            eps, sig, _ = script_util.create_edm_sigma_eps_model(**EDM32)
+            tmpl = eps.state_dict()
+            for k in tmpl:
+                if k.endswith("resample_filter"):
+                    tmpl[k] = torch.ones_like(tmpl[k]) / 4.0
+            eps.load_state_dict(fill_state_dict(tmpl, seed=0))
+            sig.load_state_dict(fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES))
+            eps.to(device).set_compute_dtype(dtype)
+            sig.to(device).set_compute_dtype(dtype)
+            self.exp = EDMImageExperiment(eps, None, batch_size=self.batch, data_shape=(3, 32, 32), seed=0, device=device,
+                                          num_timesteps=self.steps)
+            self.exp.set_model(eps, sig, learn_epsvar=False)
+            self.exp.set_norm_maxmin(0.0, 54.63)
+        self.headline = False
+        self.metric = f"images/sec, EDM 32x32 Heun+NLC, {self.steps} sigma steps"
+        self.workload = (f"EDM SongUNet 32x32 (src/edm_networks.py, 128 ch, mult 2-2-2), Heun + NLC 'pred_partial,pred', {self.steps} sigma steps "
+                         f"({2 * self.steps - 1} evaluations), f64 state, batch {self.batch} per GPU, {args.dtype}, filler weights")
+        self.gflop_per_image = (2 * self.steps - 1) * GF_EDM_EVAL
+
+    def inputs(self, n_total, world, rank):
+        from diffusion_nlc_amd import shard
+        from diffusion_nlc_amd.experiments import StackedRandomGenerator
+        out = []
+        for j in shard.owned_batches(n_total, world, rank):                  # per-sample host generators, seeds = global sample index
+            g = StackedRandomGenerator(self.device, range(j * self.batch, (j + 1) * self.batch))
+            out.append(g.randn(self.shape))
+        return out
+
+    def run(self, lat):
+        return self.exp.edm_sampler(shape=self.shape, latents=lat, style="pred_partial,pred", norm_eps="000", eps_ratio=0.5,
+                                    eps_scale=1.0, use_second_order=True)
+
+    def cpu_baseline(self):
+        from diffusion_nlc_amd import script_util
+        from diffusion_nlc_amd.filler import fill_state_dict
+        from oracle import edm
+        from oracle.loop import EdmOracle
+        torch.set_num_threads(_host_cores())
+        eps, sig, _ = script_util.create_edm_sigma_eps_model(**EDM32)
+        tmpl = eps.state_dict()
+        for k in tmpl:
+            if k.endswith("resample_filter"):
+                tmpl[k] = torch.ones_like(tmpl[k]) / 4.0
+        sd_e = fill_state_dict(tmpl, seed=0)
+        sd_s = fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES)
+        cfg = edm.EdmConfig(img_resolution=32, in_channels=3, out_channels=3, augment_dim=9, model_channels=128, channel_mult=(2, 2, 2),
+                            num_blocks=4, attn_resolutions=(16,), sigma_block=2)
+        _, dim = edm.sigma_dims(cfg)
+        B, steps = 16, 3
+        o = EdmOracle(lambda x, t: edm.unet(sd_e, cfg, x, t, "forward"), lambda x, t: edm.unet(sd_e, cfg, x, t, "encode"),
+                      lambda f: edm.sigma_net(sd_s, dim, cfg.sigma_block, f), (3, 32, 32), num_timesteps=steps, norm_min=0.0, norm_max=54.63)
+        lat = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+        n, t0 = 0, time.perf_counter()
+        while n == 0 or (time.perf_counter() - t0 < 15.0 and n < 8):
+            o.edm_sampler(lat, style="pred_partial,pred", norm_eps="000", eps_ratio=0.5, eps_scale=1.0, use_second_order=True)
             n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / (50.0 * dt), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} DDIM+NLC timestep(s) of ADM-{res} at B=1 in f32 on the host ({dt:.2f} s each), extrapolated to 50 timesteps"}
+        dt = (time.perf_counter() - t0) / n / (2 * steps - 1) / B             # s per image per evaluation
+        return {"value": 1.0 / ((2 * self.steps - 1) * dt), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} x ({steps}-step Heun+NLC = {2 * steps - 1} evaluations) at B={B} in f32/f64 on the host, extrapolated to {2 * self.steps - 1} evaluations"}
+
+
+class CelebaWorkload:
+    """BASELINE.json configs[3]: CelebA-HQ-256 'simple' UNet, inpainting restoration (seeded random 50 % mask,
+    functions/svd_operators.py:324-359), 100-step DDIM+NLC, batch 8; the projection is fused into nlc_sched_step."""
+    name = "celebahq256"
+
+    def __init__(self, args, device, dtype):
+        from diffusion_nlc_amd import script_util
+        from diffusion_nlc_amd.constraint_functions import Constraint_Function, Inpainting
+        from diffusion_nlc_amd.experiments import ImageExperiment
+        from diffusion_nlc_amd.filler import fill_state_dict
+        from diffusion_nlc_amd.schedulers import get_sampler
+        ns = argparse.Namespace
+        self.batch, self.timesteps, self.device, self.res = args.batch or 8, args.timesteps or 100, device, 256
+        self.shape = (self.batch, 3, 256, 256)
+        self.exp = None
+        if not args.dry_run:
+            config = ns(model=ns(**CELEBAHQ), data=ns(image_size=256), diffusion=ns(num_diffusion_timesteps=1000))
+            eps, sig, _ = script_util.create_simple_sigma_eps_model(config)
+            eps.load_state_dict(fill_state_dict(eps.state_dict(), seed=0))
+            sig.load_state_dict(fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES))
+            eps.to(device).set_compute_dtype(dtype)
+            sig.to(device).set_compute_dtype(dtype)
+            s = get_sampler("ddim", 1000, self.timesteps, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+            s.to(device)
+            self.exp = ImageExperiment(eps, s, batch_size=self.batch, data_shape=(3, 256, 256), seed=5, device=device)
+            self.exp.set_model(eps, sig, learn_epsvar=False)
+            self.exp.set_norm_maxmin(0.0, 397.0)                             # image_sample.py:171-174
+            self.exp.set_clip_fn("clamp")
+            g = torch.Generator().manual_seed(11)
+            missing_r = torch.randperm(256 * 256, generator=g)[: 256 * 256 // 2].long() * 3
+            missing = torch.cat([missing_r, missing_r + 1, missing_r + 2], dim=0)
+            self.op = Inpainting(3, 256, missing, device)
+            self.cf = Constraint_Function("inpainting_random", self.op, channels=3, image_size=256)
+            x_gt = torch.rand(self.shape, generator=g) * 2 - 1
+            self.bound = self.cf.bind(self.op.A(x_gt), self.shape)
+        self.headline = False
+        self.metric = f"images/sec, CelebA-HQ 256x256 inpainting, {self.timesteps}-step DDIM+NLC"
+        self.workload = (f"simple UNet 256x256 (src/unet_simple.py, ch 128, mult 1-1-2-2-4-4), inpainting (random 50 % mask), {self.timesteps}-step "
+                         f"DDIM+NLC, batch {self.batch} per GPU, {args.dtype}, clamp clip, fixedsmall variance, filler weights")
+        self.gflop_per_image = self.timesteps * GF_CELEBA_STEP
+
+    def inputs(self, n_total, world, rank):
+        from diffusion_nlc_amd import shard
+        zs = shard.draw_initial_noise(self.shape, n_total, 5, world, rank)
+        if self.exp is None:
+            return [z.to(self.device) for z in zs]
+        sigma0 = self.exp.scheduler.sampling_sigmas[0]
+        return [(z / (1 / (sigma0 ** 2 + 1)).sqrt()).to(self.device) for z in zs]
+
+    def run(self, xT):
+        x, _ = self.exp.denoise_loop(shape=self.shape, xT=xT, style="pred", constrain_fn=self.bound, norm_eps=True, refine_prior_sigma=True,
+                                     return_log=False, chunk_size=1, sigma_pred_threshold=960, return_on_device=True)
+        return x
+
+    def cpu_baseline(self):
+        from diffusion_nlc_amd import script_util
+        from diffusion_nlc_amd.filler import fill_state_dict
+        from oracle import simple
+        from oracle.loop import DiffusionOracle
+        from oracle.sched import get_sampler
+        torch.set_num_threads(_host_cores())
+        ns = argparse.Namespace
+        config = ns(model=ns(**CELEBAHQ), data=ns(image_size=256), diffusion=ns(num_diffusion_timesteps=1000))
+        eps, sig, _ = script_util.create_simple_sigma_eps_model(config)
+        sd_e = fill_state_dict(eps.state_dict(), seed=0)
+        sd_s = fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES)
+        cfg = simple.SimpleConfig(ch=128, out_ch=3, ch_mult=(1, 1, 2, 2, 4, 4), num_res_blocks=2, attn_resolutions=(16,), in_channels=3,
+                                  resolution=256, resamp_with_conv=True, feat_layer=1, sigma_block=2)
+        _, dim = simple.sigma_dims(cfg)
+        s = get_sampler("ddim", 1000, self.timesteps, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+        o = DiffusionOracle(lambda x, t: simple.unet(sd_e, cfg, x, t, "forward"), lambda x, t: simple.unet(sd_e, cfg, x, t, "encode"),
+                            lambda f: simple.sigma_net(sd_s, dim, cfg.sigma_block, f), s, (3, 256, 256), learn_epsvar=False,
+                            norm_min=0.0, norm_max=397.0, clip_fn="clamp")
+        z = torch.randn((1, 3, 256, 256), generator=torch.Generator().manual_seed(5))
+        xt = z / (1 / (s.sampling_sigmas[0] ** 2 + 1)).sqrt()
+        n, t0 = 0, time.perf_counter()
+        with torch.no_grad():
+            while n < 20 and (n == 0 or time.perf_counter() - t0 < 15.0):
+                eps_, lv, st, sp = o.get_denoise_vector(xt, s.timesteps[n], s.sampling_sigmas[n], s.sampling_sigmas[n + 1], "pred", True, True)
+                x0 = o.clip(s.pred_xstart(xt, eps_, st))
+                xt = s.pred_xprev(x0=x0, eps=eps_, sigma_t=st, sigma_prev=sp, xt=xt, log_variance=lv)
+                n += 1
+        dt = (time.perf_counter() - t0) / n
+        return {"value": 1.0 / (self.timesteps * dt), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} DDIM+NLC timestep(s) of the CelebA-HQ-256 simple UNet at B=1 in f32 on the host ({dt:.2f} s each, projection not timed), "
+                          f"extrapolated to {self.timesteps} timesteps"}
+
+
+WORKLOADS = {"adm256": AdmWorkload, "edm32": EdmWorkload, "celebahq256": CelebaWorkload}
+
+
+def _host_cores():
+    # the GPU box shares its host: a 1-GPU slot owns 16 cores (os.cpu_count() reports the whole machine)
+    return min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+
+
+def csrc_sha16():
+    """Hash of the convolution kernel sources: ties a PMC traffic profile to the build it was taken on."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "diffusion-nlc_amd" / "csrc").glob("conv_*")):
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------------
+# launcher
+# ------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks as CHILD processes - one per GPU, rendezvous on
+    127.0.0.1 - and relay their output (rank 0 prints the JSON line).  The parent never touches the GPU and never
+    re-execs itself; it only waits and returns the children's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC (RCCL between processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _host_cores() // max(args.gpus, 1))))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def main():
@@ -109,124 +353,137 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--timesteps", type=int, default=50, help="DDIM timesteps per sample (50 = the headline metric)")
+    ap.add_argument("--config", default="adm256", choices=sorted(WORKLOADS), help="adm256 = the headline metric (BASELINE.json configs[1])")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = the workload's default)")
+    ap.add_argument("--timesteps", type=int, default=0, help="sampler timesteps (0 = the workload's default; ADM-256: 50 = the headline metric)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay each network evaluation from a captured hipGraph")
     ap.add_argument("--tiny", action="store_true", help="64x64 debugging configuration (NOT the headline metric)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / sharding / gather plumbing only: no sampling (runs without a GPU under gloo); never a measurement")
     args = ap.parse_args()
 
-    from diffusion_nlc_amd import ops, shard
-    rank, world, local = shard.init_from_env("nccl")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    cfg = dict(ADM256)
-    if args.tiny:
-        cfg.update(image_size=64, num_channels=64, channel_mult="1,2,2,4", attention_resolutions="16,8", num_head_channels=32)
-    res = cfg["image_size"]
-    exp = make_experiment(cfg, device, dtype, args.batch, args.timesteps)
-    shape = (args.batch, 3, res, res)
-    n_total = (args.warmup + args.steps) * world
-    zs = shard.draw_initial_noise(shape, n_total, 1234, world, rank)          # host, reference draw order
-    sigma0 = exp.scheduler.sampling_sigmas[0]
-    xTs = [(z / (1 / (sigma0 ** 2 + 1)).sqrt()).to(device) for z in zs]       # resident in HBM before timing
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                      # before anything in this process touches the GPU
 
-    def one(xT):
-        x, _ = exp.denoise_loop(shape=shape, xT=xT, style="pred", norm_eps=True, refine_prior_sigma=True,
-                                return_log=False, chunk_size=1, sigma_pred_threshold=960)
-        return x
+    from diffusion_nlc_amd import shard
+    use_gpu = torch.cuda.is_available() and not (args.dry_run and os.environ.get("NLC_BENCH_FORCE_CPU"))
+    if not use_gpu and not args.dry_run:
+        raise SystemExit("bench.py measures the HIP path: it needs a GPU (only --dry-run runs without one)")
+    rank, world, local = shard.init_from_env("nccl" if use_gpu else "gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    wl = WORKLOADS[args.config](args, device, dtype)
+    if args.graph and wl.exp is not None:
+        wl.exp.use_graphs = True
+    n_total = (args.warmup + args.steps) * world
+    xs = wl.inputs(n_total, world, rank)                                   # resident on the device before timing
+
+    def one(x):
+        return x * 0.5 if args.dry_run else wl.run(x)
 
     def barrier():
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        one(xTs[i])
-    prof = None if args.no_roofline else []
+        one(xs[i])
     barrier()
-    ops.CONV_PROFILE = prof
     t0 = time.perf_counter()
-    outs = []
-    for i in range(args.steps):
-        outs.append(one(xTs[args.warmup + i]).to(device))
+    outs = [one(xs[args.warmup + i]) for i in range(args.steps)]           # finished samples stay on the device
     local_out = torch.stack(outs)
-    gathered = shard.gather_samples(local_out, args.steps * world, world, rank)     # the one RCCL all-gather
+    gathered = shard.gather_samples(local_out, args.steps * world, world, rank)     # the one all-gather (RCCL over xGMI)
     barrier()
     elapsed = time.perf_counter() - t0
-    ops.CONV_PROFILE = None
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
     assert gathered.shape[0] == args.steps * world and torch.isfinite(gathered).all()
 
-    images = args.batch * args.steps * world
+    images = wl.batch * args.steps * world
     line = {
-        "metric": "images/sec whole-node, 256x256 50-step DDIM+NLC" if (res == 256 and args.timesteps == 50)
-                  else f"images/sec, {res}x{res} {args.timesteps}-step DDIM+NLC (debug configuration)",
+        "metric": wl.metric if not args.dry_run else "DRY RUN (launcher / gather plumbing only, nothing sampled)",
         "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"ADM UNet {res}x{res} (src/unet_adm.py), {args.timesteps}-step DDIM+NLC, batch {args.batch} per GPU, "
-                               f"{args.dtype}, dynamic-threshold clip, learned variance, filler weights",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world} (independent samples, one all-gather)"},
+        "dtype": args.dtype, "data": "synthetic" if not args.dry_run else "none (dry run)",
+        "config": {"workload": wl.workload, "global_batch": wl.batch * world,
+                   "parallelism": f"dp{world} (independent samples, one all-gather)"},
     }
+    if args.graph:
+        line["config"]["hipgraph"] = True
     if rank == 0:
-        if prof:
-            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, d, _s in prof if d == dtype)
-            tot_fl = sum(f for _, _, f, d, _s in prof if d == dtype)
-            n = sum(1 for _, _, _, d, _s in prof if d == dtype)
-            ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            peak = PEAK_BF16_DENSE_TFLOPS if dtype == torch.bfloat16 else 157.3
-            line["roofline"] = {"bound": "mfma", "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3 on >= 32x32 maps, 75 % of its time) + conv_fast_kernel<{args.dtype},9|1> (+ splitk_reduce) + conv_igemm_kernel (strided)",
-                                "achieved": ach, "peak": peak,
-                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
-                                "avg_launch_us": 1e3 * tot_ms / max(n, 1), "avg_launch_gflop": tot_fl / max(n, 1) / 1e9,
-                                "share_of_wall": tot_ms * 1e-3 / elapsed}
-            # HBM bytes per launch of the dominant conv shape, from the separate rocprofv3 --pmc passes of the same build
-            # (profiles/r01c_pmc_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE); that shape's own
-            # launch time comes from this run's HIP events.
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_pmc_traffic.json")
-            if res == 256 and dtype == torch.bfloat16 and os.path.exists(tpath):
-                with open(tpath) as f:
-                    tj = json.load(f)
-                dom = [(e0.elapsed_time(e1), fl) for e0, e1, fl, d, shp in prof
-                       if d == dtype and shp[:4] == (args.batch * res * res, 256, 9, 256) and shp[5] == 0]
-                dominant = {"kernel": tj["kernel"], "traffic": tj["traffic_bytes_per_launch"],
-                            "algorithmic_bytes": tj["algorithmic_bytes_per_launch"],
-                            "launch_us": 1e3 * sum(t for t, _ in dom) / max(len(dom), 1),
-                            "tflops": sum(fl for _, fl in dom) / max(sum(t for t, _ in dom), 1e-9) / 1e9}
-                # per-launch average over ALL nlc_conv2d launches of a bench step (same population as `achieved`), from
-                # PMC passes over two NLC timesteps of this workload: profiles/r01f_pmc_traffic_all.json
-                apath = os.path.join(os.path.dirname(tpath), "r01f_pmc_traffic_all.json")
-                if os.path.exists(apath):
-                    with open(apath) as f:
-                        line["roofline"]["traffic"] = json.load(f)["conv2d_bytes_per_launch"]
-                else:
-                    line["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
-                line["roofline"]["traffic_of_dominant_launch"] = dominant
-            if os.environ.get("NLC_BENCH_SHAPES"):
-                agg = {}
-                for e0, e1, f, d, shp in prof:
-                    a = agg.setdefault((str(d), shp), [0, 0.0, 0.0])
-                    a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
-                for (d, shp), (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
-                    print(f"# conv {d} M={shp[0]} N={shp[1]} taps={shp[2]} Cin={shp[3]} s={shp[4]} ups={shp[5]} C1={shp[6]}: "
-                          f"{cnt} launches, {ms:.1f} ms, {fl / ms / 1e9:.0f} TFLOP/s", file=sys.stderr)
-            if res == 256:
-                line["end_to_end_tflops_per_gpu"] = (images / world) * args.timesteps * GF_PER_IMAGE_STEP / 1e3 / elapsed
-        if not args.no_cpu_baseline and not args.tiny:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+        if not args.dry_run and wl.gflop_per_image:
+            line["end_to_end_tflops_per_gpu"] = (images / world) * wl.gflop_per_image / 1e3 / elapsed
+        if not args.dry_run and not args.no_roofline:
+            line["roofline"] = roofline_leg(wl, xs[0], dtype, args)
+        if not args.dry_run and not args.no_cpu_baseline and not args.tiny and world == 1:
+            line["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def roofline_leg(wl, x, dtype, args):
+    """One more step of the same workload (outside the timed region, rank 0 only, no collective) with HIP events on the
+    launch stream around every nlc_conv2d launch."""
+    from diffusion_nlc_amd import ops
+    prof = []
+    graphs = getattr(wl.exp, "use_graphs", False)
+    wl.exp.use_graphs = False                       # events cannot be recorded per kernel inside a graph replay
+    ops.CONV_PROFILE = prof
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wl.run(x)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    finally:
+        ops.CONV_PROFILE = None
+        wl.exp.use_graphs = graphs
+    sel = [(e0.elapsed_time(e1), f, shp) for e0, e1, f, d, shp in prof if d == dtype]
+    tot_ms, tot_fl, n = sum(m for m, _, _ in sel), sum(f for _, f, _ in sel), len(sel)
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12
+    peak = PEAK_BF16_DENSE_TFLOPS if dtype == torch.bfloat16 else 157.3
+    out = {"bound": "mfma",
+           "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3 on >= 32x32 maps) + conv_fast_kernel<{args.dtype},9|1> (+ splitk_reduce) + conv_igemm_kernel",
+           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
+           "avg_launch_us": 1e3 * tot_ms / max(n, 1), "avg_launch_gflop": tot_fl / max(n, 1) / 1e9,
+           "share_of_step": tot_ms * 1e-3 / wall, "measured": "HIP events around every conv launch of one extra (untimed) step"}
+    # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+    # tagged with the hash of the kernel sources they were taken on
+    tpath = ROOT / "profiles" / "r02_pmc_traffic.json"
+    if wl.name == "adm256" and wl.res == 256 and dtype == torch.bfloat16 and tpath.exists():
+        tj = json.loads(tpath.read_text())
+        out["traffic"] = tj.get("conv2d_bytes_per_launch")
+        out["traffic_source"] = {"file": "profiles/r02_pmc_traffic.json", "csrc_sha16": tj.get("csrc_sha16"),
+                                 "matches_this_build": tj.get("csrc_sha16") == csrc_sha16()}
+        dom = [(m, f) for m, f, shp in sel if shp[:4] == (wl.batch * 256 * 256, 256, 9, 256) and shp[5] == 0]
+        if dom and "dominant" in tj:
+            out["traffic_of_dominant_launch"] = {"kernel": tj["dominant"]["kernel"], "traffic": tj["dominant"]["traffic_bytes_per_launch"],
+                                                 "algorithmic_bytes": tj["dominant"]["algorithmic_bytes_per_launch"],
+                                                 "launch_us": 1e3 * sum(m for m, _ in dom) / len(dom),
+                                                 "tflops": sum(f for _, f in dom) / sum(m for m, _ in dom) / 1e9}
+    if os.environ.get("NLC_BENCH_SHAPES"):
+        agg = {}
+        for m, f, shp in sel:
+            a = agg.setdefault(shp, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += m; a[2] += f
+        for shp, (cnt, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+            print(f"# conv M={shp[0]} N={shp[1]} taps={shp[2]} Cin={shp[3]} s={shp[4]} ups={shp[5]} C1={shp[6]}: "
+                  f"{cnt} launches, {ms:.1f} ms, {fl / ms / 1e9:.0f} TFLOP/s", file=sys.stderr)
+    return out
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NLC_HIP_LIB", _HERE / "libnlc_hip.so"))     # override: kernel A/B experiments only
 BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
 
+ABI_VERSION = 2                 # NLC_ABI_VERSION of include/nlc_hip.h
 NLC_F32, NLC_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
@@ -53,6 +54,7 @@ class ConvDesc(C.Structure):
         ("workspace_bytes", C.c_int64),
         ("stats_out", C.c_void_p),
         ("stats_bytes", C.c_int64),
+        ("policy", C.c_int32),
     ]
 
 
@@ -89,6 +91,7 @@ SIGNATURES = {
     "nlc_version": (C.c_int, []),
     "nlc_last_error": (C.c_char_p, []),
     "nlc_conv_pack_dims": (C.c_int, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nlc_pack_conv_weights": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
@@ -154,8 +157,8 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     ver = lib.nlc_version()
-    if ver != 1:
-        raise NlcError(f"libnlc_hip.so ABI version {ver} != 1")
+    if ver != ABI_VERSION:
+        raise NlcError(f"libnlc_hip.so ABI version {ver} != {ABI_VERSION}: rebuild it with `bash {BUILD_SCRIPT}`")
     _lib = lib
     return lib
 

@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import _ext
+from . import _ext, ops
 from ._ext import NlcError, check
 
 
@@ -47,6 +47,7 @@ class Inpainting:
     def singulars(self):
         return self._singulars
 
+    @ops.on_device
     def A(self, vec):
         x = vec.reshape(vec.shape[0], self.channels, -1).to(self.device, torch.float32).contiguous()
         B, C, HW = x.shape
@@ -56,6 +57,7 @@ class Inpainting:
               "nlc_inpaint_A")
         return out
 
+    @ops.on_device
     def A_pinv(self, vec):
         y = vec.reshape(vec.shape[0], -1).to(self.device, torch.float32).contiguous()
         B, nk = y.shape

@@ -239,11 +239,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
 template <typename T, int D>
 int launch(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
     using C = AttnCfg<T, D>;
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce once;
+    (void)nlc_device_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-        attr = true;
-    }
+    });
     dim3 grid(cdiv(Tn, QB), H, B);
     hipLaunchKernelGGL((attn_kernel<T, D>), grid, dim3(NTHREADS), C::LDS, st, (const T*)qkv, (T*)out, B, Tn, H);
     NLC_CHECK_LAUNCH("nlc_attention");

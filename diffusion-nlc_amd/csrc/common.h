@@ -107,3 +107,28 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Per-DEVICE one-time launch setup.  hipFuncSetAttribute (the dynamic-LDS opt-in) binds to the current device's copy of
+// the code object, so a process that drives several GPUs has to do it once per device, not once per process; the
+// CU count is a per-device fact too.  The flags are only ever set (idempotent work behind them), so two host threads
+// racing on the first launch at worst both do the setup.
+constexpr int NLC_MAX_DEVICES = 64;
+struct DeviceOnce {
+    bool done[NLC_MAX_DEVICES] = {};
+    int ncu[NLC_MAX_DEVICES] = {};
+};
+// returns the current device id (clamped into the table) and runs `setup()` the first time this device is seen
+template <typename F>
+static inline int nlc_device_once(DeviceOnce& st, F&& setup) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const int slot = dev < NLC_MAX_DEVICES ? dev : NLC_MAX_DEVICES - 1;
+    if (!st.done[slot] || dev >= NLC_MAX_DEVICES) {
+        setup();
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        st.ncu[slot] = n;
+        st.done[slot] = true;
+    }
+    return slot;
+}

@@ -438,11 +438,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
 
 template <typename T, int TAPS>
 int launch_fast(const KParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    (void)nlc_device_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL((conv_fast_kernel<T, TAPS>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), LDS_BYTES, stream, p);
     if (p.ksplit > 1) {
         const int64_t quads = (int64_t)p.M * (p.Cout >> 2);

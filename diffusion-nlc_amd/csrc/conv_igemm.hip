@@ -214,12 +214,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p
 
 template <typename T>
 int launch(const KParams& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    (void)nlc_device_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    });
     hipLaunchKernelGGL(conv_igemm_kernel<T>, dim3(p.MT * p.NT), dim3(NTHREADS), LDS_BYTES, stream, p);
     NLC_CHECK_LAUNCH("nlc_conv2d");
     return NLC_OK;
@@ -250,15 +249,14 @@ static void geometry_only(const nlc_conv_desc* d, KParams& p) {
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Cout = d->Cout;
     p.Cin_pad = d->Cin_pad; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.B = d->B;
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
-    p.ups = d->upsample2x ? 1 : 0; p.out_mode = d->out_mode;
+    p.ups = d->upsample2x ? 1 : 0; p.out_mode = d->out_mode; p.policy = d->policy;
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
 }
 
 extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
-    static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
-    if (force_generic) return 0;
+    if (d->policy == NLC_CONV_GENERIC) return 0;
     KParams p{};
     geometry_only(d, p);
     const int P = nlc_conv_halo_stats_partials(p, dtype);
@@ -309,8 +307,10 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.ksplit = 1; p.partial = nullptr;
     p.stats = nullptr; p.stats_P = 0;
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
-    // odd kernels, cropped outputs) the generic gather kernel.  NLC_CONV_GENERIC=1 forces the latter (A/B runs).
-    static const bool force_generic = getenv("NLC_CONV_GENERIC") != nullptr;
+    // odd kernels, cropped outputs) the generic gather kernel.  policy NLC_CONV_GENERIC forces the latter (A/B runs).
+    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: bad policy %d", d->policy);
+    p.policy = d->policy;
+    const bool force_generic = d->policy == NLC_CONV_GENERIC;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     (void)HL; (void)WL;
     if (!force_generic) {

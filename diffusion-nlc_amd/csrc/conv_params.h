@@ -25,6 +25,7 @@ struct KParams {
     float* partial;     // [ksplit][M][Cout] f32 (caller workspace); reduced + epilogue by splitk_reduce_kernel
     float* stats;       // conv_halo / conv_fast (bf16, NHWC out, Cout % 128 == 0) or NULL: [B][stats_P][Cout/8][2] = per 8-channel
     int stats_P;        //   chunk (sum, sum of squares) of the STORED (bf16-rounded) outputs, one partial per (patch, M-wave)
+    int policy;         // NLC_CONV_* kernel-selection policy of this call (nlc_conv_desc.policy)
 };
 
 // conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)

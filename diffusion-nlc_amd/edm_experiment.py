@@ -82,12 +82,14 @@ class EDMImageExperiment(ImageExperiment):
                                           c_skip.data_ptr(), c_out.data_ptr(), B, _s()), "nlc_edm_scalars")
         return c_in, c_noise, c_skip, c_out
 
+    @ops.on_device
     def encode_edm(self, xt, sigma):
         """:777-786 (returns NCHW f32 like the reference)."""
         xt = xt.to(self.device, torch.float64).contiguous()
         c_in, c_noise, _, _ = self._scalars(self._per_sample(sigma, xt.shape[0]))
         return self.model.run(cast_f64_f32(xt), c_noise, mode="encode", in_scale=c_in)
 
+    @ops.on_device
     def pred_edm(self, xt, sigma):
         """:788-802"""
         xt = xt.to(self.device, torch.float64).contiguous()
@@ -103,6 +105,7 @@ class EDMImageExperiment(ImageExperiment):
         return den.float()
 
     @torch.no_grad()
+    @ops.on_device
     def get_denoise_vector(self, xt, sigma_t, sigma_prev, style="base", norm_eps=False, refine_prior_sigma=False):
         """:804-843.  xt: f64 [B,C,H,W] on the device; sigma_t / sigma_prev: scalars or [B]-like.
         Returns (eps f64, denoised f64, sigma_t [B,1,1,1] f64, sigma_prev [B,1,1,1] f64)."""
@@ -143,6 +146,7 @@ class EDMImageExperiment(ImageExperiment):
         return lincomb(x, math.sqrt(self.dim) / denom)
 
     @torch.no_grad()
+    @ops.on_device
     def edm_sampler(self, shape, gen=None, style="base,base", norm_eps="000", refine_prior_sigma=False, num_steps=None,
                     sigma_scheduler="EDM", eps_ratio=0.5, eps_scale=1.0, use_second_order=True, latents=None):
         """:846-918.  ``latents`` (optional, host or device N(0,1)) replaces ``gen.randn(shape)``."""

@@ -88,6 +88,7 @@ class ExperimentDiffusion:
         self.clip_kind = clip_fn if clip_fn in ("clamp", "dynamic") else "none"
         self.clip_denoise_fn = self._clip_tensor
 
+    @ops.on_device
     def _clip_tensor(self, x):
         if self.clip_kind == "clamp":
             return x.clamp(-1, 1)
@@ -116,6 +117,7 @@ class ExperimentDiffusion:
     def new_gen(self, seed=None):
         return torch.manual_seed(self.seed if seed is None else seed)
 
+    @ops.on_device
     def get_noise(self, shape=None, gen=None, norm_noise=False):
         noise = torch.randn(self.shape if shape is None else shape, generator=self.gen if gen is None else gen)
         noise = noise.to(self.device)
@@ -124,10 +126,12 @@ class ExperimentDiffusion:
             noise = ops.scale_rows(noise, math.sqrt(self.dim) / torch.clamp(ss.sqrt(), min=1e-12))
         return noise
 
+    @ops.on_device
     def convert_coordinate(self, xt, sigma=None, t=None):
         alpha_bar = 1 / (torch.as_tensor(sigma) ** 2 + 1) if sigma is not None else self.scheduler.get_alpha_bar(t)
         return self._scale(xt, alpha_bar.sqrt())
 
+    @ops.on_device
     def inv_convert_coordinate(self, zt, sigma=None, t=None):
         alpha_bar = 1 / (torch.as_tensor(sigma) ** 2 + 1) if sigma is not None else self.scheduler.get_alpha_bar(t)
         return self._scale(zt, 1 / alpha_bar.sqrt())
@@ -138,6 +142,7 @@ class ExperimentDiffusion:
             return ops.scale_rows(x.contiguous(), None, float(s))
         return ops.scale_rows(x.contiguous(), s.to(x.device).contiguous(), 1.0)
 
+    @ops.on_device
     def get_noise_xt(self, shape=None, gen=None, norm_noise=False, t=None, sigma=None):
         """Initial state: drawn AND scaled on the host exactly as the reference does (z / sqrt(alpha_bar),
         src/experiments.py:284-293,322-325), then uploaded once per batch."""
@@ -148,12 +153,15 @@ class ExperimentDiffusion:
         xt = z / alpha_bar.sqrt()
         return xt.to(self.device, torch.float32).contiguous(), z.to(self.device)
 
+    @ops.on_device
     def pred_xt(self, xt, t, sigma=None, batch_t=True):
         return self.model(self.convert_coordinate(xt, sigma, t), self._t_vec(t, len(xt), batch_t))
 
+    @ops.on_device
     def encode_xt(self, xt, t, sigma=None, batch_t=True):
         return self.model.encode(self.convert_coordinate(xt, sigma, t), self._t_vec(t, len(xt), batch_t))
 
+    @ops.on_device
     def forward_and_encode_xt(self, xt, t, sigma=None, batch_t=True):
         return self.model.forward_and_encode(self.convert_coordinate(xt, sigma, t), self._t_vec(t, len(xt), batch_t))
 
@@ -253,6 +261,7 @@ class ExperimentDiffusion:
         return x0_hat, x0, x_prev, eps_used
 
     @torch.no_grad()
+    @ops.on_device
     def get_denoise_vector(self, xt, t, sigma_t, sigma_prev, style="base", norm_eps=False, refine_prior_sigma=False,
                            chunk_size=2):
         """Reference-shaped wrapper: returns (eps_mean, eps_logvar, sigma_t, sigma_prev) as (B,..) GPU tensors."""
@@ -268,12 +277,15 @@ class ExperimentDiffusion:
         return eps, self.scheduler.get_eps_logvar(sig_t, sig_p, learned), sig_t, sig_p
 
     @torch.no_grad()
+    @ops.on_device
     def denoise_loop(self, shape, gen=None, norm_init_noise=False, style="base", constrain_fn=None, norm_eps=False,
                      refine_prior_sigma=False, xT=None, return_log=True, chunk_size=2, sigma_pred_threshold=1000,
-                     new_eta=None, constrain_loss=None, return_best=True, free_const_steps=-1, noise_list=None):
+                     new_eta=None, constrain_loss=None, return_best=True, free_const_steps=-1, noise_list=None,
+                     return_on_device=False):
         """src/experiments.py:329-397.  ``noise_list`` (optional) supplies the per-step N(0,1) draws that
         stochastic samplers consume; by default they come from the global CPU generator, one
-        ``randn(shape)`` per step, in step order."""
+        ``randn(shape)`` per step, in step order.  ``return_on_device`` keeps the returned sample in HBM (the
+        reference returns it on the CPU, :396; the sharded driver gathers it over RCCL first)."""
         S = self.scheduler
         S.reset_state()
         dev = self.device
@@ -340,10 +352,13 @@ class ExperimentDiffusion:
             elif self.check_nan and int(st["nan"].item()) != 0:       # torch.isnan(xt).any() -> break (:389)
                 break
         S.eta = eta0
-        out = (best_x0 if return_best else x0).cpu()
+        out = best_x0 if return_best else x0
+        if not return_on_device:
+            out = out.cpu()
         return out, [z_list, eps_list, x0_prec_list, x0_postc_list, const_loss_list]
 
     @torch.no_grad()
+    @ops.on_device
     def projection_loop(self, shape, gen=None, norm_init_noise=False, style="base", constrain_fn=None, norm_eps=False,
                         refine_prior_sigma=False, xT=None, return_log=False, chunk_size=2, sigma_estimate_rate=(1, 0, 0, 0),
                         constrain_loss=None, stop_condition=0.0, max_T=None, sigma_pred_threshold=1000, new_eta=None,

@@ -236,11 +236,11 @@ class SigmaHead:
 
     def __init__(self, sd, device, act: int, allow_split: bool = False):
         self.allow_split = allow_split
-        w, b = sd["fc_layer.1.weight"].double(), sd["fc_layer.1.bias"].double()
         g, beta = sd["fc_layer.2.weight"].double(), sd["fc_layer.2.bias"].double()
         mean, var = sd["fc_layer.2.running_mean"].double(), sd["fc_layer.2.running_var"].double()
-        s = g / torch.sqrt(var + 1e-5)
-        self.fc = ops.pack_conv((w * s[:, None]).float(), ((b - mean) * s + beta).float(), torch.float32, device)
+        s = g / torch.sqrt(var + 1e-5)                  # f64: the fold itself happens inside nlc_pack_conv_weights
+        self.fc = ops.pack_conv(sd["fc_layer.1.weight"], sd["fc_layer.1.bias"], torch.float32, device, row_scale=s,
+                                bias_add=beta - mean * s)
         self.final = ops.pack_conv(sd["final_mlp.weight"], sd["final_mlp.bias"], torch.float32, device)
         self.act = act
 

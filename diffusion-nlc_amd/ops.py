@@ -7,6 +7,7 @@ channels-last ``[B, H, W, C]`` tensors in the compute dtype (torch.float32 or to
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -16,6 +17,20 @@ import torch
 from . import _ext
 from ._ext import (ACT_GELU, ACT_NONE, ACT_SILU, NLC_BF16, NLC_F32, OUT_NCHW_F32, OUT_NHWC,
                    ConvDesc, SchedDesc, check)
+
+
+def on_device(fn):
+    """Method decorator: run ``fn`` with ``self.device`` as the current HIP device.  Every shim below launches on
+    ``torch.cuda.current_stream()`` - the CURRENT device's stream - so an object bound to cuda:K must make K current
+    around its launches (and around the allocations feeding them), whatever device the caller left selected."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        dev = torch.device(getattr(self, "device", "cpu"))
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                return fn(self, *a, **k)
+        return fn(self, *a, **k)
+    return wrapper
 
 
 def dtype_enum(dtype: torch.dtype) -> int:
@@ -67,37 +82,43 @@ class PackedConv:
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype, device,
               row_perm: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
-              col_perm: Optional[torch.Tensor] = None) -> PackedConv:
-    """Pack a torch-layout weight ([Cout,Cin,KH,KW], [Cout,Cin,K] or [Cout,Cin]) once at load time.
+              col_perm: Optional[torch.Tensor] = None, bias_add: Optional[torch.Tensor] = None) -> PackedConv:
+    """Pack a torch-layout weight ([Cout,Cin,KH,KW], [Cout,Cin,K] or [Cout,Cin]) once at load time, on the device,
+    through nlc_pack_conv_weights (the layout, permutation and folding rules live behind the C ABI).
 
     row_perm / row_scale reorder and scale output channels (used to bring the reference's qkv
-    channel orders into the canonical [3][H][D] order and to fold the attention scale);
-    col_perm reorders input features (NCHW-flatten -> NHWC-flatten for the sigma head).
+    channel orders into the canonical [3][H][D] order and to fold the attention scale or an eval-mode
+    BatchNorm); bias_add is added to the (permuted, scaled) bias; col_perm reorders input features.
     """
-    w = weight.detach().to(torch.float32).cpu()
+    lib = _ext.load()
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _ext.NlcError("pack_conv: weights are packed on the GPU (no CPU fallback)")
+    w = weight.detach()
     if w.dim() == 2:
         w = w[:, :, None, None]
     elif w.dim() == 3:
         w = w[:, :, :, None]
-    b = None if bias is None else bias.detach().to(torch.float32).cpu().clone()
-    if col_perm is not None:
-        w = w[:, col_perm]
-    if row_perm is not None:
-        w = w[row_perm]
-        if b is not None:
-            b = b[row_perm]
-    if row_scale is not None:
-        w = w * row_scale.view(-1, 1, 1, 1)
-        if b is not None:
-            b = b * row_scale
     Cout, Cin, KH, KW = w.shape
     cout_mult, cin_mult = _ext.pack_dims(dtype_enum(dtype))
     Cin_pad, Cout_pad = _round_up(Cin, cin_mult), _round_up(Cout, cout_mult)
-    packed = torch.zeros(Cout_pad, KH * KW, Cin_pad, dtype=torch.float32)
-    packed[:Cout, :, :Cin] = w.permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin)
-    return PackedConv(w=packed.to(device=device, dtype=dtype).contiguous(),
-                      bias=None if b is None else b.to(device).contiguous(),
-                      Cin=Cin, Cout=Cout, KH=KH, KW=KW, Cin_pad=Cin_pad, Cout_pad=Cout_pad, dtype=dtype)
+    with torch.cuda.device(device):
+        wd = w.to(device=device, dtype=torch.float32).contiguous()
+        bd = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        rp = None if row_perm is None else row_perm.to(device=device, dtype=torch.int32).contiguous()
+        cp = None if col_perm is None else col_perm.to(device=device, dtype=torch.int32).contiguous()
+        rs = None if row_scale is None else row_scale.detach().to(device=device, dtype=torch.float64).contiguous()
+        ba = None if bias_add is None else bias_add.detach().to(device=device, dtype=torch.float64).contiguous()
+        for nm, v, n in (("row_perm", rp, Cout), ("row_scale", rs, Cout), ("bias_add", ba, Cout), ("col_perm", cp, Cin)):
+            if v is not None and v.numel() != n:
+                raise ValueError(f"pack_conv: {nm} must have {n} entries")
+        packed = torch.empty(Cout_pad, KH * KW, Cin_pad, device=device, dtype=dtype)
+        has_bias = bd is not None or ba is not None
+        bout = torch.empty(Cout, device=device, dtype=torch.float32) if has_bias else None
+        check(lib.nlc_pack_conv_weights(wd.data_ptr(), _ptr(bd), Cout, Cin, KH, KW, _ptr(rp), _ptr(rs), _ptr(ba), _ptr(cp),
+                                        dtype_enum(dtype), packed.data_ptr(), _ptr(bout), _stream()), "nlc_pack_conv_weights")
+        torch.cuda.current_stream().synchronize()      # load time: the f32 staging copies may be freed after this
+    return PackedConv(w=packed, bias=bout, Cin=Cin, Cout=Cout, KH=KH, KW=KW, Cin_pad=Cin_pad, Cout_pad=Cout_pad, dtype=dtype)
 
 
 # --------------------------------------------------------------------------------------
@@ -106,6 +127,12 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
 # When bench.py sets this to a list, every nlc_conv2d launch appends (start_event, end_event,
 # algorithmic FLOPs = 2*M*N*K of the direct convolution, dtype).
 CONV_PROFILE = None
+# Kernel-selection policy handed to every nlc_conv2d call (nlc_conv_desc.policy): "auto" is the production dispatch;
+# tests and A/B tools pin a kernel with "halo" (LDS-halo kernel for every eligible shape), "no_halo" or "generic".
+CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3}
+CONV_POLICY = "auto"
+
+
 def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
            pad: Optional[tuple] = None, out_hw: Optional[tuple] = None, upsample2x: bool = False,
            emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
@@ -160,7 +187,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  upsample2x=1 if upsample2x else 0, w=pw.w.data_ptr(), Cin_pad=pw.Cin_pad, Cout_pad=pw.Cout_pad,
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
-                 out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC)
+                 out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY])
     stats = None
     if dt == torch.bfloat16 and emit_stats and not out_nchw_f32 and not linear:
         # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel

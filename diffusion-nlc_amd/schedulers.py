@@ -264,7 +264,8 @@ class Scheduler:
         d = SchedDesc(xt=xt.contiguous().data_ptr(), eps_out=eps.contiguous().data_ptr(), sigma_t=st.data_ptr(),
                       sigma_prev=st.data_ptr(), x0=x0.data_ptr(), B=B, C=Cc, Cnet=Cc, HW=xt.numel() // (B * Cc),
                       variant=0, clip=0, var_mode=0, phases=0, eta=0.0, min_var_coef=float(self.min_var_coef))
-        ops.sched_x0(d)
+        with torch.cuda.device(xt.device):
+            ops.sched_x0(d)
         return x0
 
     def pred_xprev(self, x0, eps, sigma_t, sigma_prev, xt=None, log_variance=None, noise=None):
@@ -294,7 +295,8 @@ class Scheduler:
                       eta=float(self.eta), min_var_coef=float(self.min_var_coef))
         # keep temporaries alive until the launch is enqueued
         self._keep = (st, sp, lv, noise, x0c, xtc)
-        ops.sched_step(d)
+        with torch.cuda.device(dev):
+            ops.sched_step(d)
         self.i += 1
         return xp
 

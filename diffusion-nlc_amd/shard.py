@@ -60,13 +60,11 @@ def gather_samples(local: torch.Tensor, n_batches: int, world: int, rank: int) -
     pad = n_max - local.shape[0]
     if pad:
         local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
-    gathered = local.new_empty((world,) + tuple(local.shape))
+    gathered = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(gathered.view(-1), local.contiguous().view(-1))
-    out = local.new_empty((n_batches,) + tuple(local.shape[1:]))
-    for r in range(world):
-        for i, j in enumerate(owned_batches(n_batches, world, r)):
-            out[j] = gathered[r, i]
-    return out
+    # global batch j was sampled by rank j % world as its (j // world)-th batch: one gather-by-index on the device
+    j = torch.arange(n_batches, device=local.device)
+    return gathered.index_select(0, (j % world) * n_max + j // world)
 
 
 def sample_sharded(run_batch: Callable[[torch.Tensor], torch.Tensor], batch_shape: Sequence[int], n_batches: int,

@@ -98,6 +98,8 @@ def main(args):
         model.load_state_dict(torch.load(args.load_eps, map_location="cpu"))
         sigma_model.load_state_dict(torch.load(args.load_sigma, map_location="cpu"))
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if torch.device(args.device).type == "cuda":
+        torch.cuda.set_device(torch.device(args.device))       # --device cuda:K: every launch below goes to K's streams
     model.eval().to(args.device).set_compute_dtype(dt)
     sigma_model.eval().to(args.device).set_compute_dtype(dt)
 

@@ -371,6 +371,8 @@ def main(args, config):
     else:
         model.load_state_dict(torch.load(args.load_eps, map_location="cpu"))
         sigma_model.load_state_dict(torch.load(args.load_sigma, map_location="cpu"))
+    if torch.device(args.device).type == "cuda":
+        torch.cuda.set_device(torch.device(args.device))       # --device cuda:K: every launch below goes to K's streams
     model.eval().to(args.device)
     sigma_model.eval().to(args.device)
     if getattr(mc, "use_fp16", False):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 1
+#define NLC_ABI_VERSION 2
 
 enum { NLC_F32 = 0, NLC_BF16 = 1 };
 enum { NLC_OK = 0, NLC_EINVAL = -1, NLC_ELAUNCH = -2, NLC_EUNSUPPORTED = -3 };
@@ -45,6 +45,11 @@ enum {
 };
 enum { NLC_CLIP_NONE = 0, NLC_CLIP_CLAMP = 1, NLC_CLIP_DYNAMIC = 2 };
 enum { NLC_VAR_NONE = 0, NLC_VAR_FIXEDSMALL = 1, NLC_VAR_FIXEDLARGE = 2, NLC_VAR_LEARNED = 3 };
+/* kernel-selection policy of one nlc_conv2d call (nlc_conv_desc.policy).  AUTO is the production dispatch: the
+ * LDS-halo kernel for stride-1 3x3 "same" convolutions with >= 256 (16x16 pixel x 128 channel) tiles, else the LDS-DMA
+ * implicit-GEMM kernel (3x3 / 1x1), else the generic gather kernel.  The others exist so that parity tests and A/B
+ * timings can pin a kernel per call; there is no process-wide switch. */
+enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3 };
 
 int nlc_version(void);
 const char* nlc_last_error(void);
@@ -52,6 +57,26 @@ const char* nlc_last_error(void);
 /* Tile geometry the host needs to pack weights: Cout is padded to a multiple of
  * *cout_mult rows and Cin to a multiple of *cin_mult elements (zero filled). */
 int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult);
+
+/* Pack one convolution / linear weight for nlc_conv2d, on the device (load time, once per tensor):
+ *   w        : the reference's own layout, f32 [Cout][Cin][KH*KW]  (nn.Conv2d / Conv1d(k=1) / Linear .weight, contiguous)
+ *   packed   : [Cout_pad][KH*KW][Cin_pad] in the compute dtype, zero padded; Cout_pad / Cin_pad = Cout / Cin rounded up to
+ *              the multiples nlc_conv_pack_dims reports
+ *   packed[r][tap][c] = (T)( (double) w[row_perm ? row_perm[r] : r][col_perm ? col_perm[c] : c][tap] * (row_scale ? row_scale[r] : 1) )
+ *   bias_out[r]       = (float)( (double) bias[row_perm ? row_perm[r] : r] * (row_scale ? row_scale[r] : 1) + (bias_add ? bias_add[r] : 0) )
+ * which covers every load-time fold of this path:
+ *   row_perm   int32 [Cout]   output-channel order: the reference's qkv layouts -> the canonical [q|k|v][head][ch]
+ *                             (legacy [head][q|k|v][ch], src/unet_adm.py:347; new order :380-388)
+ *   row_scale  f64   [Cout]   per-output-channel factor: the attention scale ch^-1/4 on q and k (src/unet_adm.py:348-351),
+ *                             1/sqrt(C) on k (src/edm_networks.py:127), BatchNorm1d(eval) gamma/sqrt(var+eps)
+ *                             (src/unet_adm.py:1056)
+ *   bias_add   f64   [Cout]   BatchNorm's beta - mean*gamma/sqrt(var+eps)
+ *   col_perm   int32 [Cin]    input-feature order: NCHW-flatten -> NHWC-flatten of the sigma head's Linear (:1055)
+ * bias may be NULL (then bias_out is written only if bias_add is given; a NULL bias counts as 0); bias_out may be NULL
+ * when neither exists.  All pointers are device pointers. */
+int nlc_pack_conv_weights(const float* w, const float* bias, int Cout, int Cin, int KH, int KW,
+                          const int32_t* row_perm, const double* row_scale, const double* bias_add,
+                          const int32_t* col_perm, int dtype, void* packed, float* bias_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Convolution / linear as one implicit-GEMM MFMA kernel.
@@ -90,6 +115,7 @@ typedef struct nlc_conv_desc {
                          /* float [B][P][Cout/8][2] = (sum, sum of squares) of the STORED values per 8-channel chunk and     */
                          /* partial; P = nlc_conv2d_stats_partials(desc, dtype) must be > 0 (bf16, NHWC, Cout % 128 == 0,    */
                          /* launches that take the LDS-halo kernel).  Consumed by nlc_groupnorm_prestats.                    */
+    int32_t policy;      /* NLC_CONV_* (0 = AUTO); the three queries below honour it like nlc_conv2d does */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);

@@ -1,14 +1,9 @@
-import os
 import sys
 from pathlib import Path
 
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-# The LDS-halo conv kernel is dispatched in production only when a launch has >= 256 tiles; the parity tests run small
-# shapes, so they force it for every eligible shape (read once by the library, before its first conv launch).
-# Shapes it does not take (ragged channel blocks, non-16-multiple maps, upsample, 1x1, strided) still reach the other kernels.
-os.environ.setdefault("NLC_CONV_HALO", "1")
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
@@ -25,3 +20,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# The convolution kernel is chosen per call (nlc_conv_desc.policy).  Every GPU parity module that runs convolutions is
+# collected TWICE: under the production dispatch ("auto": what bench.py measures - the LDS-halo kernel only for launches
+# with >= 256 tiles, otherwise conv_fast / split-K / the generic kernel) and with the LDS-halo kernel forced for every
+# eligible shape (the small parity shapes would otherwise never reach it).
+@pytest.fixture(params=["auto", "halo"], ids=["production-dispatch", "forced-halo"])
+def conv_policy(request):
+    from diffusion_nlc_amd import ops
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = request.param
+    yield request.param
+    ops.CONV_POLICY = old

@@ -5,7 +5,7 @@ SURVEY.md §8e), finiteness / range, and agreement of the bf16 first step with t
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_policy")]
 
 
 @pytest.fixture(scope="module")
@@ -57,18 +57,16 @@ def test_adm256_bf16_first_step_tracks_f32(adm256):
     assert torch.isfinite(out_bf).all() and err <= 6e-2 * scale and rel_rms <= 2e-2
 
 
-def test_adm256_f32_two_steps_match_the_oracle_at_full_size(adm256):
-    """The headline model itself (ADM-256, 614 M parameters, 256x256) in f32 against the CPU oracle: two full
-    DDIM+NLC timesteps (refine -> encode -> sigma net -> corrected sigma / t -> eps forward -> learned variance,
-    dynamic-threshold clip -> scheduler update) for one image; per-pixel L-inf <= 1e-3 (the north-star tolerance).
-    ~1.5 s of oracle time per timestep on the GPU box's 16 host cores."""
+@pytest.fixture(scope="module")
+def adm256_oracle():
+    """The CPU oracle on the headline model itself (ADM-256, 614 M parameters, 256x256): two full DDIM+NLC timesteps of one
+    image (~1.5 s of oracle time per timestep on the GPU box's 16 host cores).  Returns (xT, final sample, per-step trace)."""
     import bench
     from diffusion_nlc_amd.filler import fill_state_dict
     from diffusion_nlc_amd.script_util import create_sigma_eps_model
     from oracle import adm
     from oracle.loop import DiffusionOracle
     from oracle.sched import get_sampler as oracle_sampler
-    exp = adm256
     cfg = dict(bench.ADM256)
     ucfg, scfg, _ = adm.configs_from_factory(**cfg)
     eps_m, sig_m, _ = create_sigma_eps_model(**cfg)
@@ -83,7 +81,18 @@ def test_adm256_f32_two_steps_match_the_oracle_at_full_size(adm256):
     z = torch.randn((1, 3, 256, 256), generator=torch.Generator().manual_seed(99))
     xT = z / (1 / (osched.sampling_sigmas[0] ** 2 + 1)).sqrt()
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    x_cpu = o.denoise_loop((1, 3, 256, 256), style="pred", norm_eps=True, refine_prior_sigma=True, xT=xT, sigma_pred_threshold=960)
+    trace = {}
+    x_cpu = o.denoise_loop((1, 3, 256, 256), style="pred", norm_eps=True, refine_prior_sigma=True, xT=xT, sigma_pred_threshold=960,
+                           trace=trace)
+    return xT, x_cpu, trace
+
+
+def test_adm256_f32_two_steps_match_the_oracle_at_full_size(adm256, adm256_oracle):
+    """The headline model in f32 against the CPU oracle: two full DDIM+NLC timesteps (refine -> encode -> sigma net ->
+    corrected sigma / t -> eps forward -> learned variance, dynamic-threshold clip -> scheduler update) for one image;
+    per-pixel L-inf <= 1e-3 (the north-star tolerance).  Runs under the production dispatch and with the halo kernel forced."""
+    exp = adm256
+    xT, x_cpu, _ = adm256_oracle
     exp.model.set_compute_dtype(torch.float32)
     exp.sigma_model.set_compute_dtype(torch.float32)
     try:
@@ -95,6 +104,37 @@ def test_adm256_f32_two_steps_match_the_oracle_at_full_size(adm256):
     err = (x_gpu.double() - x_cpu.double()).abs().max().item()
     print(f"ADM-256 f32, 2 DDIM+NLC timesteps, 1 image: HIP vs CPU oracle L-inf = {err:.3e}")
     assert err <= 1e-3, err
+
+
+# bf16 (the benchmarked dtype) against the ORACLE at full size.  Gates are what the measurement supports:
+# the first timestep's x0 - one encode + sigma net + forward through bf16 convolutions, everything else f32 - and the
+# sigma the NLC net corrected; a multi-step bf16 trajectory of a random-weight network is not pixel-comparable
+# (discontinuous sigma -> t lookup), which is why the 1e-3 gate is carried by the f32 path above.
+# Measured on MI355X (round 2): x0 L-inf 0.39, RMS 0.061 against an x0 RMS of 0.80 - at sigma_0 = 100 the first x0 is
+# xt - 100 * eps, the difference of two ~100-sized tensors, so the ~0.9 % bf16 error of eps (test above) is amplified ~10x
+# before the dynamic-threshold normalisation.  Gated at ~1.5x the measured values.
+BF16_X0_LINF, BF16_X0_RMS, BF16_SIGMA_REL = 0.6, 0.09, 0.02
+
+
+def test_adm256_bf16_first_step_against_the_oracle_at_full_size(adm256, adm256_oracle):
+    exp = adm256
+    xT, _, trace = adm256_oracle
+    x0_cpu = trace["x0"][0]                                              # post-clip x0 of timestep 0, in [-1, 1]
+    _, logs = exp.denoise_loop(shape=(1, 3, 256, 256), xT=xT, style="pred", norm_eps=True, refine_prior_sigma=True,
+                               return_log=True, chunk_size=1, sigma_pred_threshold=960)
+    x0_gpu = logs[3][0]
+    d = (x0_gpu.double() - x0_cpu.double())
+    linf, rms = d.abs().max().item(), d.pow(2).mean().sqrt().item()
+    ref_rms = x0_cpu.double().pow(2).mean().sqrt().item()
+    print(f"ADM-256 bf16, first DDIM+NLC timestep, 1 image, x0 vs CPU oracle: L-inf {linf:.3e}, RMS {rms:.3e} (x0 RMS {ref_rms:.3e})")
+    assert torch.isfinite(x0_gpu).all() and linf <= BF16_X0_LINF and rms <= BF16_X0_RMS
+    # the corrected sigma of timestep 0 (what NLC is for): rerun that one step and read the device state
+    S = exp.scheduler                                                    # the fixture's 2-step schedule = the oracle's
+    exp._nlc_step(xT.to("cuda:0"), float(S.timesteps[0]), S.sampling_sigmas[0], S.sampling_sigmas[1], "pred", True, True)
+    sig0 = exp._state(1)["sigma_t"].cpu().double()
+    rel = ((sig0 - trace["sigma_t"][0].double()).abs() / trace["sigma_t"][0].double()).max().item()
+    print(f"ADM-256 bf16, NLC-corrected sigma of timestep 0 vs CPU oracle: relative error {rel:.3e}")
+    assert rel <= BF16_SIGMA_REL
 
 
 def test_celebahq256_inpainting_f32_matches_the_oracle_at_full_size():

@@ -56,7 +56,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libnlc_hip.so does not export {name}"
         assert name in _ext.SIGNATURES, f"{name} is declared in nlc_hip.h but not bound in _ext.py"
     assert set(_ext.SIGNATURES) <= declared
-    assert lib.nlc_version() == 1
+    assert lib.nlc_version() == _ext.ABI_VERSION
     a, b = _ext.pack_dims(_ext.NLC_BF16)
     assert a % 16 == 0 and b % 8 == 0
 

@@ -13,7 +13,7 @@ from tests.test_host_cpu import build_product
 from tests.test_nets_gpu import _models
 from tests.util import load_npz, max_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_policy")]
 
 LOOPS = ["loop_simple_pred", "loop_simple_base", "loop_simple_partial", "loop_simple_orig_eta", "loop_simple_threshold",
          "loop_adm_dynamic", "loop_adm_eta", "loop_admb_ddpm"]

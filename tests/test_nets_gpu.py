@@ -10,7 +10,7 @@ import torch
 from tests.test_host_cpu import build_product
 from tests.util import load_npz, max_err, oracle_nets, state_dicts
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("conv_policy")]
 TAGS = ["adm_tiny", "adm_tiny_b", "simple_tiny", "edm_tiny"]
 
 

@@ -70,12 +70,19 @@ CONV_CASES = [
     dict(B=2, Cin=256, H=8, W=8, Cout=128, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
     dict(B=1, Cin=512, H=8, W=8, Cout=72, k=3, act="silu", nchw=True),
     dict(B=2, Cin=1024, H=4, W=4, Cout=256, k=1, res=True),
+    # 16x16 / 32x32 maps with too few tiles for the halo kernel under the production dispatch: conv_fast<9> with split-K
+    # (4 / 8 / 2 splits in bf16; f32 never splits) and without it - the 16x16 / 32x32 levels of ADM-256
+    dict(B=2, Cin=512, H=16, W=16, Cout=256, k=3, emb=True, res=True),
+    dict(B=1, Cin=1024, H=16, W=16, Cout=384, k=3, split=512, act="silu"),
+    dict(B=2, Cin=256, H=32, W=32, Cout=128, k=3, res=True, scale=math.sqrt(0.5)),
+    dict(B=4, Cin=64, H=32, W=32, Cout=128, k=3, act="silu"),
+    dict(B=2, Cin=128, H=16, W=16, Cout=256, k=3, ups=True, res=True),                 # fused upsample outside the halo kernel
 ]
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d(case, dtype):
+def test_conv2d(case, dtype, conv_policy):
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(hash(str(case)) % (1 << 31))
     B, Cin, H, W, Cout, k = (case[x] for x in ("B", "Cin", "H", "W", "Cout", "k"))
@@ -281,9 +288,10 @@ def test_row_sumsq_and_quantile():
     assert torch.equal(ops.dynamic_threshold(z.to(_dev()), 0.99, 100.0).cpu(), torch.tensor([3.0, 3.0]))
 
 
-def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them():
-    """bf16 LDS-halo conv: the epilogue's per-8-channel (sum, sumsq) partials describe the STORED output exactly enough,
-    and GroupNorm fed with them (two passes) agrees with the three-pass GroupNorm and with the f32 reference."""
+def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
+    """bf16 conv (LDS-halo kernel when forced, conv_fast<9> under the production dispatch): the epilogue's per-8-channel
+    (sum, sumsq) partials describe the STORED output exactly enough, and GroupNorm fed with them (two passes) agrees with the
+    three-pass GroupNorm and with the f32 reference."""
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(11)
     B, Cin, H, W, Cout = 2, 64, 32, 48, 256
@@ -294,7 +302,9 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them():
     pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
     y = ops.conv2d(_nhwc(x, torch.bfloat16), pw, res=_nhwc(res, torch.bfloat16), act=1)
     st = getattr(y, "_nlc_stats", None)
-    assert st is not None and st.shape == (B, (H // 16) * (W // 16) * 4, Cout // 8, 2)
+    # partials per image: 4 per 16x16 patch from the halo kernel, 2 per 128-pixel tile from conv_fast
+    P = (H // 16) * (W // 16) * 4 if conv_policy == "halo" else (H * W // 128) * 2
+    assert st is not None and st.shape == (B, P, Cout // 8, 2)
     yf = y.float().cpu()                                              # [B,H,W,C] stored values
     chunks = yf.view(B, H * W, Cout // 8, 8)
     ref_sum, ref_sq = chunks.sum(dim=(1, 3)), (chunks.double() ** 2).sum(dim=(1, 3))
@@ -327,3 +337,78 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them():
     scale = ref.abs().max().item()
     assert (fused.float().cpu() - plain.float().cpu()).abs().max().item() <= 2e-2 * scale      # one bf16 ulp of slack
     assert (fused.float().cpu() - ref).abs().max().item() <= 2e-2 * scale
+
+
+STAT_CASES = [
+    # (B, Cin, H, W, Cout, expected partials per image under the production dispatch, what emits them)
+    (2, 512, 16, 16, 256, 256, "split-K reduce: one partial per pixel"),
+    (1, 1024, 16, 16, 1024, 256, "split-K reduce, the ADM-256 16x16 level"),
+    (2, 256, 32, 32, 128, 1024, "split-K reduce on a 32x32 map"),
+    (4, 64, 32, 32, 128, 16, "conv_fast<9> epilogue: two partials per 128-pixel tile"),
+    (16, 128, 32, 32, 512, 16, "halo kernel, 256 tiles: four partials per 16x16 patch"),
+]
+
+
+@pytest.mark.parametrize("case", STAT_CASES, ids=lambda c: f"B{c[0]}-Cin{c[1]}-{c[2]}x{c[3]}-Cout{c[4]}")
+def test_ride_along_statistics_under_the_production_dispatch(case):
+    """The statistics every bf16 GroupNorm of the benchmarked path consumes, from each kernel that emits them under the
+    PRODUCTION dispatch (ops.groupnorm trusts the attached buffer blindly): sums over partials == sums over the stored
+    output, for every 8-channel chunk; then GroupNorm with and without them."""
+    from diffusion_nlc_amd import ops
+    B, Cin, H, W, Cout, P_expect, what = case
+    g = torch.Generator().manual_seed(B * 1000 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.3 + 0.5
+    res = torch.randn(B, Cout, H, W, generator=g)
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "auto"
+    try:
+        y = ops.conv2d(_nhwc(x, torch.bfloat16), ops.pack_conv(w, b, torch.bfloat16, _dev()), res=_nhwc(res, torch.bfloat16))
+    finally:
+        ops.CONV_POLICY = old
+    st = getattr(y, "_nlc_stats", None)
+    assert st is not None and st.shape == (B, P_expect, Cout // 8, 2), (what, None if st is None else st.shape)
+    ref = F.conv2d(_rt(x, torch.bfloat16), _rt(w, torch.bfloat16), b, padding=1) + _rt(res, torch.bfloat16)
+    _close(y.permute(0, 3, 1, 2), ref, 2e-2, what)
+    ch = y.float().cpu().view(B, H * W, Cout // 8, 8).double()
+    got = st.double().sum(dim=1).cpu()
+    s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
+    assert (got[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0), what
+    assert ((got[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3, what
+    gamma, beta = torch.randn(Cout, generator=g).to(_dev()), torch.randn(Cout, generator=g).to(_dev())
+    fused = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=True)
+    ops.FUSED_GN_STATS = False
+    try:
+        plain = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=True)
+    finally:
+        ops.FUSED_GN_STATS = True
+    refn = F.silu(F.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, gamma.cpu(), beta.cpu(), eps=1e-5)).permute(0, 2, 3, 1)
+    scale = refn.abs().max().item()
+    assert (fused.float().cpu() - plain.float().cpu()).abs().max().item() <= 2e-2 * scale, what
+    assert (fused.float().cpu() - refn).abs().max().item() <= 2e-2 * scale, what
+
+
+def test_pack_conv_weights_abi_matches_the_host_packing_rule():
+    """nlc_pack_conv_weights (device) against the packing rule written out on the host: layout, padding, output-row
+    permutation, per-row f64 scale (attention scale / BatchNorm fold), bias fold, input-column permutation."""
+    from diffusion_nlc_amd import _ext, ops
+    g = torch.Generator().manual_seed(4)
+    for dtype in DTYPES:
+        Cout, Cin, k = 72, 40, 3
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        b = torch.randn(Cout, generator=g)
+        rp = torch.randperm(Cout, generator=g)
+        cp = torch.randperm(Cin, generator=g)
+        rs = torch.rand(Cout, generator=g, dtype=torch.float64) + 0.5
+        ba = torch.randn(Cout, generator=g, dtype=torch.float64)
+        pw = ops.pack_conv(w, b, dtype, _dev(), row_perm=rp, row_scale=rs, col_perm=cp, bias_add=ba)
+        cm, km = _ext.pack_dims(ops.dtype_enum(dtype))
+        assert pw.w.shape == ((Cout + cm - 1) // cm * cm, k * k, (Cin + km - 1) // km * km) and pw.w.dtype == dtype
+        want = (w[rp][:, cp].double() * rs.view(-1, 1, 1, 1)).float().permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)
+        got = pw.w.float().cpu()
+        assert torch.equal(got[:Cout, :, :Cin], want.to(dtype).float())
+        assert got[Cout:].abs().max() == 0 and got[:, :, Cin:].abs().max() == 0
+        assert torch.equal(pw.bias.cpu(), (b[rp].double() * rs + ba).float())
+    lin = ops.pack_conv(torch.randn(10, 20, generator=g), None, torch.float32, _dev())
+    assert lin.bias is None and lin.KH == 1 and lin.Cin == 20

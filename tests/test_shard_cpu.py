@@ -59,3 +59,29 @@ def test_ownership_and_noise_order():
     for r in range(2):
         mine = shard.draw_initial_noise(SHAPE, 4, 7, 2, r)
         assert all(torch.equal(a, ref[j]) for a, j in zip(mine, shard.owned_batches(4, 2, r)))
+
+
+def test_bench_self_launches_its_ranks_under_gloo():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two rank processes itself (before it
+    touches any device), they rendezvous over gloo on 127.0.0.1, shard the batches, all-gather, and rank 0's JSON line
+    comes back through the parent with n_gpus = 2.  --dry-run replaces the sampling (which needs the HIP path) by a
+    stand-in so that the launcher / sharding / gather plumbing is what runs here."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NLC_BENCH_FORCE_CPU"] = "1"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--tiny"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 32 and "DRY RUN" in line["metric"]
+    # a rank that dies must fail the whole command
+    bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0            # no GPU here and no --dry-run: every rank refuses
