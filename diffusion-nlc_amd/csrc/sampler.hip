@@ -355,7 +355,8 @@ int check_sched(const nlc_sched_desc* d, const char* name) {
     if (d->B > 65535) { nlc_set_error("%s: B too large", name); return NLC_EINVAL; }
     if ((int64_t)d->C * d->HW >= (1ll << 31)) { nlc_set_error("%s: sample too large", name); return NLC_EINVAL; }
     if (d->variant < NLC_SCHED_DDIM || d->variant > NLC_SCHED_DDIM_ORIG) { nlc_set_error("%s: bad variant %d", name, d->variant); return NLC_EINVAL; }
-    if (d->var_mode == NLC_VAR_LEARNED && !d->logvar_ext && d->Cnet < 2 * d->C) {   // a caller-supplied log-variance overrides var_mode nlc_set_error("%s: learned variance needs Cnet >= 2C", name); return NLC_EINVAL; }
+    // (a caller-supplied log-variance overrides var_mode)
+    if (d->var_mode == NLC_VAR_LEARNED && !d->logvar_ext && d->Cnet < 2 * d->C) { nlc_set_error("%s: learned variance needs Cnet >= 2C", name); return NLC_EINVAL; }
     if ((d->mask == nullptr) != (d->known == nullptr)) { nlc_set_error("%s: mask/known must come together", name); return NLC_EINVAL; }
     return NLC_OK;
 }
