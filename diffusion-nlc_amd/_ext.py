@@ -55,6 +55,7 @@ class ConvDesc(C.Structure):
         ("stats_out", C.c_void_p),
         ("stats_bytes", C.c_int64),
         ("policy", C.c_int32),
+        ("tuning", C.c_int32),
     ]
 
 

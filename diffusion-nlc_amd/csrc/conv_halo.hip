@@ -97,6 +97,7 @@ struct TileH { int tb, y0, x0, n0; };
 __device__ unsigned long long g_halo_clock[4];     // {s_memtime, s_memrealtime} at loop start / end of workgroup 0, wave 0
 __device__ unsigned long long g_halo_stamps[8][8];
 __device__ unsigned long long g_halo_epi[8][6];    // inside the epilogue of tile 1: start, cadd loads issued, pixel loop done, stats done, acc re-initialised
+__device__ unsigned long long g_halo_steps[8][12];  // per wave: s_memtime at the start of each of the 9 taps of (tile 1, cb 1) + at the end of tap 8
 __device__ unsigned long long g_halo_tile[8][4];   // per wave: s_memtime before / after the epilogues of tiles 1 and 2 of workgroup 0
 #define STAMP(i) do { if (stamp_on && tap == HALO_STAMP_TAP) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define STAMP_FLUSH() do { if (stamp_on && tap == HALO_STAMP_TAP && lane == 0) { for (int q_ = 0; q_ < 8; ++q_) g_halo_stamps[wave][q_] = st[q_]; } } while (0)
@@ -168,13 +169,16 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         for (int j = 0; j < NA; ++j) {
             const int R = (wave + 8 * j) * 8 + lrow;
             const int hy = R / HALO, hx = R - hy * HALO;
-            const int iy = t.y0 + hy - 1, ix = t.x0 + hx - 1;
+            // tuning 4: timing experiment (WRONG results): every tile fetches the halo of a fixed patch of image 0 -> the rows
+            // are L2 / Infinity-Cache resident instead of streaming from HBM
+            const bool fix = (p.tuning & 4) != 0;
+            const int iy = (fix ? 16 : t.y0) + hy - 1, ix = (fix ? 16 : t.x0) + hx - 1;
             // (iy, ix) are coordinates in the conv's (possibly virtual, nearest-2x upsampled) input = output grid; with the
             // upsample fused the halo row is fetched from source pixel (iy >> 1, ix >> 1) - the LDS image holds the
             // upsampled patch, so the k-loop does not know about it (src/unet_adm.py:107-109)
             const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout;
             const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
-            const int64_t pixel = ((int64_t)t.tb * p.Hin + sy) * p.Win + sx;
+            const int64_t pixel = ((int64_t)(fix ? 0 : t.tb) * p.Hin + sy) * p.Win + sx;
             haddr[j] = ok ? src + (pixel * C + hchunk * PER) * ES : zero;
         }
     };
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #ifdef HALO_STAMP
             const bool stamp_on = blockIdx.x == 0 && tl == wi + gx && cb == 1;
             unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long stp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
             auto step = [&](auto tap_c) {
                 constexpr int tap = decltype(tap_c)::value;
@@ -516,6 +521,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                         }
                     }
                 };
+#ifdef HALO_STAMP
+                if (stamp_on) { __builtin_amdgcn_sched_barrier(0); stp[tap] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
                 STAMP(0);
                 // Each half: 8 fragment reads for a LATER cluster + 16 MFMAs.  The sched_group_barrier pattern makes the
                 // backend interleave them as [1 ds_read, 2 MFMA] x 8 instead of "all reads, then all MFMAs": an MFMA holds
@@ -559,6 +567,12 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
             step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+#ifdef HALO_STAMP
+            if (stamp_on) {
+                __builtin_amdgcn_sched_barrier(0); stp[9] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+                if (lane == 0) { for (int q_ = 0; q_ < 10; ++q_) g_halo_steps[wave][q_] = stp[q_]; }
+            }
+#endif
             hs ^= 1;
         }
 #ifdef HALO_STAMP
@@ -602,6 +616,7 @@ extern "C" int nlc_debug_halo_stamps(unsigned long long* out) {
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(g_halo_clock), sizeof(unsigned long long) * 4);
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 68, HIP_SYMBOL(g_halo_tile), sizeof(unsigned long long) * 32);
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 100, HIP_SYMBOL(g_halo_epi), sizeof(unsigned long long) * 48);
+    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 148, HIP_SYMBOL(g_halo_steps), sizeof(unsigned long long) * 96);
     return rc;
 }
 #endif

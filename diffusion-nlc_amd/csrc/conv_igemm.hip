@@ -309,7 +309,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  policy NLC_CONV_GENERIC forces the latter (A/B runs).
     NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: bad policy %d", d->policy);
-    p.policy = d->policy;
+    p.policy = d->policy; p.tuning = d->tuning;
     const bool force_generic = d->policy == NLC_CONV_GENERIC;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     (void)HL; (void)WL;

@@ -26,6 +26,7 @@ struct KParams {
     float* stats;       // conv_halo / conv_fast (bf16, NHWC out, Cout % 128 == 0) or NULL: [B][stats_P][Cout/8][2] = per 8-channel
     int stats_P;        //   chunk (sum, sum of squares) of the STORED (bf16-rounded) outputs, one partial per (patch, M-wave)
     int policy;         // NLC_CONV_* kernel-selection policy of this call (nlc_conv_desc.policy)
+    int tuning;         // A/B switches (nlc_conv_desc.tuning)
 };
 
 // conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)

@@ -131,6 +131,7 @@ CONV_PROFILE = None
 # tests and A/B tools pin a kernel with "halo" (LDS-halo kernel for every eligible shape), "no_halo" or "generic".
 CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3}
 CONV_POLICY = "auto"
+CONV_TUNING = 0              # nlc_conv_desc.tuning: schedule A/B switches for tools/ (0 in production)
 
 
 def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
@@ -187,7 +188,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  upsample2x=1 if upsample2x else 0, w=pw.w.data_ptr(), Cin_pad=pw.Cin_pad, Cout_pad=pw.Cout_pad,
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
-                 out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY])
+                 out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY], tuning=CONV_TUNING)
     stats = None
     if dt == torch.bfloat16 and emit_stats and not out_nchw_f32 and not linear:
         # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel

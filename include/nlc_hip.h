@@ -116,6 +116,8 @@ typedef struct nlc_conv_desc {
                          /* partial; P = nlc_conv2d_stats_partials(desc, dtype) must be > 0 (bf16, NHWC, Cout % 128 == 0,    */
                          /* launches that take the LDS-halo kernel).  Consumed by nlc_groupnorm_prestats.                    */
     int32_t policy;      /* NLC_CONV_* (0 = AUTO); the three queries below honour it like nlc_conv2d does */
+    int32_t tuning;      /* 0 in production.  Bit mask of kernel A/B switches for in-process timing experiments (tools/): */
+                         /* results are identical for every value, only the schedule changes (see conv_halo.hip).          */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);

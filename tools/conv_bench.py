@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", type=int, default=-1, help="run only SHAPES[i] (for rocprofv3 --pmc passes)")
+    ap.add_argument("--tuning", default="0", help="comma list of nlc_conv_desc.tuning values to A/B, interleaved in this one process")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a ResBlock)")
     args = ap.parse_args()
     global SHAPES
     if args.only >= 0:
@@ -45,18 +48,29 @@ def main():
         w = torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)
         pw = ops.pack_conv(w, torch.zeros(cout), dt, dev)
         ups = note.endswith("ups")
+        Ho = 2 * H if ups else H
+        res = torch.randn(args.batch, Ho, Ho, cout, device=dev).to(dt) if args.res else None
+        tunings = [int(t) for t in args.tuning.split(",")]
         for _ in range(3):
-            ops.conv2d(x, pw, upsample2x=ups)
+            ops.conv2d(x, pw, upsample2x=ups, res=res)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.reps):
-            ops.conv2d(x, pw, upsample2x=ups)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.reps
         fl = 2.0 * args.batch * H * H * cout * cin * k * k * (4 if ups else 1)
-        print(f"{note:32s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.0f} TFLOP/s", flush=True)
+        times = {t: [] for t in tunings}
+        for _ in range(args.rounds):                      # variants interleaved round by round in ONE process
+            for t in tunings:
+                ops.CONV_TUNING = t
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    ops.conv2d(x, pw, upsample2x=ups, res=res)
+                e1.record()
+                torch.cuda.synchronize()
+                times[t].append(e0.elapsed_time(e1) / args.reps)
+        ops.CONV_TUNING = 0
+        for t in tunings:
+            v = sorted(times[t])
+            med, mn = v[len(v) // 2], v[0]
+            print(f"{note:32s} tuning={t}  median {med * 1e3:9.1f} us {fl / med / 1e9:7.0f} TFLOP/s   min {mn * 1e3:9.1f} us {fl / mn / 1e9:7.0f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@
 set -euo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 src="$root/diffusion-nlc_amd/csrc"
-out="$root/gpurun_out/stamp"
+out="$root/build/stamp"
 mkdir -p "$out"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHALO_STAMP -DHALO_STAMP_TAP=${HALO_STAMP_TAP:-4} -I"$root/include" -I"$src" -c "$src/conv_halo.hip" -o "$out/conv_halo_stamp.o"
 objs=$(ls "$src"/obj/*.o | grep -v conv_halo.o)
