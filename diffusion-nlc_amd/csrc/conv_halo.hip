@@ -169,16 +169,13 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         for (int j = 0; j < NA; ++j) {
             const int R = (wave + 8 * j) * 8 + lrow;
             const int hy = R / HALO, hx = R - hy * HALO;
-            // tuning 4: timing experiment (WRONG results): every tile fetches the halo of a fixed patch of image 0 -> the rows
-            // are L2 / Infinity-Cache resident instead of streaming from HBM
-            const bool fix = (p.tuning & 4) != 0;
-            const int iy = (fix ? 16 : t.y0) + hy - 1, ix = (fix ? 16 : t.x0) + hx - 1;
+            const int iy = t.y0 + hy - 1, ix = t.x0 + hx - 1;
             // (iy, ix) are coordinates in the conv's (possibly virtual, nearest-2x upsampled) input = output grid; with the
             // upsample fused the halo row is fetched from source pixel (iy >> 1, ix >> 1) - the LDS image holds the
             // upsampled patch, so the k-loop does not know about it (src/unet_adm.py:107-109)
             const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout;
             const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
-            const int64_t pixel = ((int64_t)(fix ? 0 : t.tb) * p.Hin + sy) * p.Win + sx;
+            const int64_t pixel = ((int64_t)t.tb * p.Hin + sy) * p.Win + sx;
             haddr[j] = ok ? src + (pixel * C + hchunk * PER) * ES : zero;
         }
     };
