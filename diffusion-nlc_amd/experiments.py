@@ -69,6 +69,17 @@ class ExperimentDiffusion:
         self.fid_fn = None
         self.gen = self.new_gen()
 
+    # ---- hipGraph replay of the network evaluations (HipModule._graphable) ------------------------
+    @property
+    def use_graphs(self):
+        return bool(getattr(self.model, "use_graphs", False))
+
+    @use_graphs.setter
+    def use_graphs(self, flag):
+        for m in (self.model, self.sigma_model):
+            if m is not None and hasattr(m, "drop_graphs"):
+                m.use_graphs = bool(flag)
+
     # ---- configuration (src/experiments.py:104-114,176-226) -------------------------------------
     def set_model(self, model=None, sigma_model=None, learn_epsvar=True):
         if model is not None:

@@ -23,7 +23,7 @@ def _stats(a):
     return torch.stack([a.flatten(2).mean(-1), a.flatten(2).abs().mean(-1)], dim=-1)
 
 
-def run_hip_loop(g, dtype=torch.float32, return_log=True):
+def run_hip_loop(g, dtype=torch.float32, return_log=True, graphs=False):
     from diffusion_nlc_amd.experiments import ImageExperiment
     from diffusion_nlc_amd.schedulers import get_sampler
     c = g["cfg"]
@@ -35,6 +35,7 @@ def run_hip_loop(g, dtype=torch.float32, return_log=True):
     exp.set_model(eps, sig, learn_epsvar=c["tag"] == "adm_tiny")
     exp.set_norm_maxmin(c["norm_min"], c["norm_max"])
     exp.set_clip_fn(c["clip"])
+    exp.use_graphs = graphs
     shape = (c["B"], 3, c["res"], c["res"])
     ng = torch.Generator().manual_seed(c["seed"] + 1)
     noises = [torch.randn(shape, generator=ng) for _ in range(int(g["n_noise"]))] or None
@@ -70,6 +71,20 @@ def test_bf16_loop_tracks_reference(name):
     # (builds whose f32-side kernels differ by 1-2 ulp move this statistic between 4.7e-2 and 5.4e-2 on the ADM
     #  fixture - dynamic thresholding divides by a per-sample quantile - so the gate is a loose 1e-1)
     assert torch.isfinite(x).all() and first < 1e-1
+
+
+@pytest.mark.parametrize("name,dtype", [("loop_adm_dynamic", torch.float32), ("loop_adm_dynamic", torch.bfloat16),
+                                        ("loop_simple_threshold", torch.float32), ("loop_admb_ddpm", torch.bfloat16)])
+def test_hipgraph_replay_is_bit_identical_to_eager_launches(name, dtype):
+    """Network evaluations replayed from captured hipGraphs (one per entry point / shape; the threshold fixture switches
+    between the NLC and the plain branch mid-run, the DDPM one injects host noise every step) against the same loop with
+    every kernel launched eagerly: the same kernels on the same data -> equal bit for bit, and several replays deep."""
+    g = load_npz(name)
+    x_eager, _ = run_hip_loop(g, dtype=dtype, return_log=False)
+    x_graph, _ = run_hip_loop(g, dtype=dtype, return_log=False, graphs=True)
+    assert torch.equal(x_graph, x_eager)
+    if dtype == torch.float32:
+        assert max_err(x_graph, g["x"]) < 1e-3
 
 
 def test_loop_without_logging_is_identical():
