@@ -236,6 +236,218 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16, head dim 64, T a multiple of 256: the shape of every attention block of the ADM-256 UNet (T = 1024 / 256, 64
+// channels per head).  Everything stays in registers between the two matrix products:
+//   * 512 threads = 8 waves, each wave owns 32 query rows of a 256-row query block of one (batch, head); the 64-key K / V
+//     tiles are shared by the 8 waves and arrive by LDS-DMA (one 1-KiB piece of K and one of V per wave and tile, source-side
+//     swizzle), double buffered, one barrier per tile;
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = the wave's Q rows, loaded once): lane (q = l & 31,
+//     h = l >> 5) then holds 32 of the 64 scores of ITS query row, so the row maximum is 16 v_max3 + one half exchange
+//     (v_permlane32_swap) and the exponentials / row sums are lane-local - no shuffles, no LDS;
+//   * O^T = V^T P^T reuses the score registers directly as the B operand (an accumulator tile is the next MFMA's operand
+//     for a product that sums over its ROW index; cdna_hip_programming.md §3): registers 8s..8s+7 of a 32-key block, cast
+//     to bf16, are k-step s, in the k order key = 16 s + 8 (j >> 2) + 4 h + (j & 3).  The V^T fragments are read from the
+//     row-major V tile in that same key order with two ds_read_b64_tr_b16 each;
+//   * O^T has the query on the lane as well, so the online-softmax rescale and the final 1 / l are lane-local too.
+// exp(x) is evaluated as exp2(x log2 e) with the multiply folded into one FMA per score.
+constexpr int FQ_WAVES = 8, FQ_ROWS = 256, FKV = 64;
+constexpr int F_SUB = 1;                               // 64-key tiles per stage (= per barrier); 2 measured slower (55.9 vs 51.7 us at T = 1024)
+constexpr int F_TILE = FKV * 128;                      // one K or V tile: 64 rows x 128 B
+constexpr int F_STAGE = F_SUB * F_TILE;
+constexpr int F_LDS = 4 * F_STAGE;                     // K0 K1 V0 V1 = 32 KiB
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ int fk_swz(int row) { return (row >> 1) & 7; }                              // ds_read_b128 of K rows
+__device__ __forceinline__ int fv_swz(int row) { return ((row & 3) << 1) | ((row >> 2) & 1); }          // ds_read_b64_tr_b16 of V
+
+__device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gptr), "s"(__builtin_amdgcn_readfirstlane(lds_base))
+                 : "memory");
+}
+
+__global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out,
+                                                                    int Tn, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    // XCD-aware block order: the query blocks of one (batch, head) read the same K / V, so they should run on the same
+    // XCD (its L2 then serves all but the first read).  Workgroup ids are dealt round-robin over the 8 XCDs; XCD x
+    // (= id & 7) takes a contiguous chunk of the [pair][query block] list (bijective for any block count).
+    const int nqb = Tn / FQ_ROWS, nblk = gridDim.x;
+    int lin;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, cq = nblk >> 3, cr = nblk & 7;
+        lin = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
+    }
+    const int pair = lin / nqb, qblk = lin - pair * nqb;
+    const int b = pair / H, hd = pair - b * H, q0 = qblk * FQ_ROWS + wave * 32;
+    const int64_t tok = (int64_t)3 * H * 64;            // elements between consecutive tokens
+    const bf16_raw* qb = qkv + (int64_t)b * Tn * tok + (int64_t)hd * 64;
+    const bf16_raw* kb = qb + (int64_t)H * 64;
+    const bf16_raw* vb = qb + (int64_t)2 * H * 64;
+
+    // Q^T fragments (B operand): lane (q, h) holds Q[q0 + q][16 s + 8 h + j], j = 0..7
+    bf16x8_t qf[4];
+    {
+        const bf16_raw* qp = qb + (int64_t)(q0 + q) * tok + h * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qp + s * 16));
+    }
+
+    // this wave's DMA piece of every tile: rows 8 wave .. 8 wave + 7; lane -> (row, 16-byte slot), source chunk = slot ^ swizzle(row)
+    const int drow = wave * 8 + (lane >> 3), dslot = lane & 7;
+    const bf16_raw* ksrc = kb + (int64_t)drow * tok + ((dslot ^ fk_swz(drow)) << 3);
+    const bf16_raw* vsrc = vb + (int64_t)drow * tok + ((dslot ^ fv_swz(drow)) << 3);
+    const unsigned dma_off = (unsigned)wave * 1024u;
+    auto issue = [&](int tile, int stage) {               // `tile` counts stages of F_SUB x 64 keys
+#pragma unroll
+        for (int u = 0; u < F_SUB; ++u) {
+            const int64_t o = (int64_t)(tile * F_SUB + u) * FKV * tok;
+            attn_glds16(ksrc + o, lds0 + stage * F_STAGE + u * F_TILE + dma_off);
+            attn_glds16(vsrc + o, lds0 + (2 + stage) * F_STAGE + u * F_TILE + dma_off);
+        }
+    };
+
+    // per-lane LDS offsets (within a tile): K row reads and V transposed reads
+    int koff[4];                                         // key block kb2 adds 32 rows = 4096 bytes (same swizzle: (row >> 1) & 7 ignores bit 5)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) koff[s] = q * 128 + (((2 * s + h) ^ fk_swz(q)) << 4);
+    // V^T fragment of (16-key step ks, 32-column block db): two transposed reads, rows r0 = 16 ks + 4 h + qq (+ 8), columns
+    // db * 32 + 16 cb + 4 pp .. + 3  with  cb = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3
+    const int cb = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    auto voff = [&](int ks, int db, int second) {
+        const int row = 16 * ks + 4 * h + qq + 8 * second;
+        const int colb = (db * 32 + cb * 16 + 4 * pp) * 2;
+        return row * 128 + ((((colb >> 4)) ^ fv_swz(row)) << 4) + (colb & 15);
+    };
+    int vo[4][2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { vo[ks][db][0] = voff(ks, db, 0); vo[ks][db][1] = voff(ks, db, 1); }
+
+    f32x16_t o0, o1;                                     // O^T blocks: d = 32 db + (reg & 3) + 8 (reg >> 2) + 4 h, query on the lane
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m = -1e30f, l = 0.f;                           // running maximum (of score * log2 e) and this lane's half of the row sum
+    constexpr float L2E = 1.44269504088896340736f;
+
+    const int ntiles = Tn / (FKV * F_SUB);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the compiler's own bookkeeping must also see the Q loads as complete HERE: otherwise it waits for them with counted
+    // vmcnt(N) inside the loop, and since it cannot see the asm DMAs those counts drain each tile's prefetch at once
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int st = t & 1;
+        if (t + 1 < ntiles) issue(t + 1, st ^ 1);        // the other stage was last read during tile t - 1 (barrier passed)
+#pragma unroll
+      for (int u = 0; u < F_SUB; ++u) {
+        const char* Kt = smem + st * F_STAGE + u * F_TILE;
+        const char* Vt = smem + (2 + st) * F_STAGE + u * F_TILE;
+        // ---- S^T = K Q^T : two 32-key blocks
+        f32x16_t s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8_t ka = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Kt + koff[s]));
+            const bf16x8_t kc = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Kt + koff[s] + 4096));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, qf[s], s1, 0, 0, 0);
+        }
+        // ---- online softmax, lane-local except one half exchange for the maximum
+        // Row maximum of the RAW scores with v_max3_f32 from inline asm: fmaxf() on an MFMA output makes hipcc insert a
+        // quieting v_max(x, x) per element first (32 extra VALU per tile in a loop that is VALU-issue bound).  The first
+        // maximum is plain C so that the compiler itself pads the MFMA -> VALU read hazard of both accumulators; every asm
+        // statement depends on it through `tm`.
+        float tm = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(s0[r]), "v"(s1[r]));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tm), __float_as_uint(tm), false, false);
+            tm = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));      // lanes l and l ^ 32 hold the two halves of one row
+        }
+        const float mn = fmaxf(m, tm * L2E);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {       // wave-uniform: after the first tiles the maximum rarely moves
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], L2E, -mn));
+            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], L2E, -mn));
+            l += s0[r];
+            l += s1[r];
+        }
+        // ---- O^T += V^T P^T : P^T k-steps come straight from the score registers
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)((ks < 2 ? s0 : s1)[(ks & 1) * 8 + j]);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vt + vo[ks][db][0]));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vt + vo[ks][db][1]));
+                uint4 va;
+                va.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+                va.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+                va.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+                va.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+                if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, va), pf, o0, 0, 0, 0);
+                else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, va), pf, o1, 0, 0, 0);
+            }
+        }
+      }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own DMA pieces of tile t + 1 landed ...
+        __syncthreads();                                       // ... and everybody's are published; tile t's stage is free
+    }
+    // ---- finish: full row sum = both halves, normalise, store 4 consecutive channels (8 bytes) per register quad
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+        l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l;
+    bf16_raw* op = out + ((int64_t)b * Tn + q0 + q) * ((int64_t)H * 64) + (int64_t)hd * 64 + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x16_t& o = db ? o1 : o0;
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(o[4 * g] * inv) | ((unsigned)f32_to_bf16(o[4 * g + 1] * inv) << 16);
+            pk.y = (unsigned)f32_to_bf16(o[4 * g + 2] * inv) | ((unsigned)f32_to_bf16(o[4 * g + 3] * inv) << 16);
+            *reinterpret_cast<uint2*>(op + db * 32 + 8 * g) = pk;
+        }
+}
+
+int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
+    static DeviceOnce once;
+    (void)nlc_device_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    });
+    hipLaunchKernelGGL(attn_d64_kernel, dim3((Tn / FQ_ROWS) * H * B), dim3(FQ_WAVES * 64), F_LDS, st, (const bf16_raw*)qkv, (bf16_raw*)out, Tn, H);
+    NLC_CHECK_LAUNCH("nlc_attention(d64)");
+    return NLC_OK;
+}
+
 template <typename T, int D>
 int launch(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
     using C = AttnCfg<T, D>;
@@ -269,7 +481,9 @@ extern "C" int nlc_attention(const void* qkv, void* out, int B, int T, int H, in
     NLC_REQUIRE(qkv && out, "nlc_attention: null pointer");
     NLC_REQUIRE(B > 0 && T > 0 && H > 0 && D > 0, "nlc_attention: bad dims");
     NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_attention: bad dtype %d", dtype);
-    NLC_REQUIRE(H <= 65535 && B <= 65535, "nlc_attention: grid too large");
+    NLC_REQUIRE(H <= 65535 && B <= 65535 && (int64_t)B * H * (T / 64 + 1) < (1ll << 31), "nlc_attention: grid too large");
+    // the ADM-256 shapes (64 channels per head, T = 1024 / 256): register-resident kernel above
+    if (dtype == NLC_BF16 && D == 64 && T % FQ_ROWS == 0) return launch_d64(qkv, out, B, T, H, (hipStream_t)stream);
     if (dtype == NLC_BF16) return dispatch<bf16_raw>(qkv, out, B, T, H, D, (hipStream_t)stream);
     return dispatch<float>(qkv, out, B, T, H, D, (hipStream_t)stream);
 }

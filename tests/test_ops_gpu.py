@@ -186,6 +186,8 @@ ATTN_CASES = [
     dict(B=2, T=64, H=2, D=32), dict(B=1, T=256, H=4, D=64), dict(B=2, T=100, H=1, D=64),
     dict(B=2, T=4, H=2, D=64), dict(B=1, T=1024, H=2, D=64), dict(B=1, T=80, H=1, D=128),
     dict(B=1, T=48, H=1, D=256), dict(B=1, T=70, H=1, D=512),
+    # 64 channels per head, T a multiple of 256: bf16 takes the register-resident kernel (attn_d64_kernel)
+    dict(B=2, T=512, H=3, D=64), dict(B=1, T=768, H=2, D=64, spike=True),
 ]
 
 
@@ -197,6 +199,11 @@ def test_attention(case, dtype):
     B, T, H, D = case["B"], case["T"], case["H"], case["D"]
     qkv = torch.randn(B, T, 3, H, D, generator=g)
     qkv[:, :, :2] *= D ** -0.25 * 1.5          # realistic logit scale after the folded ch^-1/4
+    if case.get("spike"):
+        # force the online-softmax rescale branch late in the key loop: a few keys far above the running maximum of
+        # every query (tile 9 of 12), and one query row that also spikes against them
+        qkv[:, 600:603, 1] *= 6.0
+        qkv[:, 17, 0] *= 4.0
     r = _rt(qkv, dtype)
     q, k, v = r[:, :, 0], r[:, :, 1], r[:, :, 2]          # [B,T,H,D]
     s = torch.einsum("bthd,bshd->bhts", q, k)

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of nlc_attention on the ADM-256 shapes (B=16, D=64)."""
+"""Micro-benchmark of nlc_attention on the ADM-256 shapes (B=16, D=64).
+
+    python tools/attn_bench.py                 # all three shapes
+    python tools/attn_bench.py 1024 8 [reps]   # one shape (rocprofv3 --pmc passes)
+Inputs carry the logit scale the networks produce (q and k each scaled by ch^-1/4, unit-variance activations)."""
 import sys
 from pathlib import Path
 
@@ -8,17 +12,23 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from diffusion_nlc_amd import ops  # noqa: E402
 
-for T, H in ((1024, 8), (256, 16), (64, 16)):
-    qkv = torch.randn(16, T, 3 * H * 64, device="cuda:0").to(torch.bfloat16)
-    for _ in range(3):
-        ops.attention(qkv, H)
+shapes = ((1024, 8), (256, 16), (64, 16))
+reps = 20
+if len(sys.argv) >= 3:
+    shapes = ((int(sys.argv[1]), int(sys.argv[2])),)
+    reps = int(sys.argv[3]) if len(sys.argv) >= 4 else 20
+for T, H in shapes:
+    qkv = torch.randn(16, T, 3, H, 64, device="cuda:0")
+    qkv[:, :, :2] *= 64 ** -0.25
+    qkv = qkv.reshape(16, T, 3 * H * 64).to(torch.bfloat16)
+    out = [ops.attention(qkv, H) for _ in range(3)]
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20):
+    for _ in range(reps):
         ops.attention(qkv, H)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 20
+    ms = e0.elapsed_time(e1) / reps
     fl = 4.0 * 16 * H * T * T * 64
     print(f"attention T={T:5d} heads={H:2d} D=64  {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.0f} TFLOP/s", flush=True)
