@@ -117,6 +117,7 @@ SIGNATURES = {
     "nlc_sched_x0": (C.c_int, [C.POINTER(SchedDesc), _vp]),
     "nlc_sched_step": (C.c_int, [C.POINTER(SchedDesc), _vp, _vp]),
     "nlc_scale_rows": (C.c_int, [_vp, _vp, _f, _vp, _i, _i64, _vp]),
+    "nlc_lincomb_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "nlc_cast_f64_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "nlc_row_sumsq_f64": (C.c_int, [_vp, _vp, _i, _i64, _vp]),
     "nlc_row_cosine_f64": (C.c_int, [_vp, _vp, C.c_double, _vp, _i, _i64, _vp]),

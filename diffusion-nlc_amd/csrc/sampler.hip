@@ -348,6 +348,18 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
         out[(int64_t)b * D + i] = x[(int64_t)b * D + i] * sc;
 }
 
+// out[b,:] = ca[b]*x[b,:] + cb[b]*y[b,:], two roundings of the products and one of the sum (this file is compiled with
+// -ffp-contract=off): the forward process x_n = x_0 sqrt(abar_t) + noise sqrt(1 - abar_t), src/schedulers.py:323-329
+__global__ void lincomb_rows_kernel(const float* __restrict__ x, const float* __restrict__ ca, const float* __restrict__ y,
+                                    const float* __restrict__ cb, float* __restrict__ out, int64_t D) {
+    const int b = blockIdx.y;
+    const float a = ca[b], c = cb ? cb[b] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < D; i += (int64_t)gridDim.x * NT) {
+        const int64_t o = (int64_t)b * D + i;
+        out[o] = y ? x[o] * a + y[o] * c : x[o] * a;
+    }
+}
+
 int check_sched(const nlc_sched_desc* d, const char* name) {
     if (!d) { nlc_set_error("%s: null descriptor", name); return NLC_EINVAL; }
     if (!d->xt || !d->eps_out || !d->sigma_t || !d->sigma_prev || !d->x0) { nlc_set_error("%s: null pointer", name); return NLC_EINVAL; }
@@ -446,6 +458,16 @@ extern "C" int nlc_sched_step(const nlc_sched_desc* d, int* nan_flag, void* stre
     int gx = cdiv((int64_t)d->C * d->HW, NT * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
     hipLaunchKernelGGL(sched_step_kernel, dim3(gx, d->B), dim3(NT), 0, (hipStream_t)stream, *d, nan_flag);
     NLC_CHECK_LAUNCH("nlc_sched_step");
+    return NLC_OK;
+}
+
+extern "C" int nlc_lincomb_rows(const float* x, const float* ca, const float* y, const float* cb, float* out, int B, int64_t D,
+                                void* stream) {
+    NLC_REQUIRE(x && ca && out && B > 0 && D > 0 && B <= 65535, "nlc_lincomb_rows: bad arguments");
+    NLC_REQUIRE((y == nullptr) == (cb == nullptr), "nlc_lincomb_rows: y / cb must come together");
+    int gx = cdiv(D, NT * 4); if (gx < 1) gx = 1; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(lincomb_rows_kernel, dim3(gx, B), dim3(NT), 0, (hipStream_t)stream, x, ca, y, cb, out, D);
+    NLC_CHECK_LAUNCH("nlc_lincomb_rows");
     return NLC_OK;
 }
 

@@ -104,33 +104,57 @@ class EDMImageExperiment(ImageExperiment):
                                       sig.data_ptr(), eps.data_ptr(), den.data_ptr(), B, xt.numel() // B, _s()), "nlc_edm_eps")
         return den.float()
 
+    @staticmethod
+    def _is_scalar(v):
+        """The reference's ``len(sigma.unsqueeze(-1)) == 1`` test (src/experiments.py:811,816,829-834): a 0-dim value or a
+        one-element tensor."""
+        return v.dim() == 0 or v.shape[0] == 1
+
+    def _small(self, v):
+        """A sigma-like value as a device tensor with the reference's OWN shape and dtype (0-dim float64 for schedule
+        scalars, (B,1,1,1) for per-sample values): the per-step sigma algebra below is then plain torch on a handful of
+        elements and inherits ATen's type promotion exactly - a 0-dim f64 operand does NOT promote an f32 (B,1,1,1)
+        one, so without refine_prior_sigma the NLC products of the reference are float32 (src/experiments.py:824-825)."""
+        if torch.is_tensor(v):
+            return v.to(self.device)
+        return torch.as_tensor(v, dtype=torch.float64, device=self.device)
+
     @torch.no_grad()
     @ops.on_device
     def get_denoise_vector(self, xt, sigma_t, sigma_prev, style="base", norm_eps=False, refine_prior_sigma=False):
-        """:804-843.  xt: f64 [B,C,H,W] on the device; sigma_t / sigma_prev: scalars or [B]-like.
-        Returns (eps f64, denoised f64, sigma_t [B,1,1,1] f64, sigma_prev [B,1,1,1] f64)."""
+        """:804-843, op by op.  xt: f64 [B,C,H,W] on the device; sigma_t / sigma_prev: scalars (0-dim) or (B,1,1,1).
+        Returns (eps f64, denoised f64, sigma_t, sigma_prev) with the reference's shapes ((1,1,1,1) for scalars) and dtypes."""
         B = xt.shape[0]
         D = xt.numel() // B
-        sig_t, sig_p = self._per_sample(sigma_t, B), self._per_sample(sigma_prev, B)
-        sig_orig = sig_t
+        sigma_t, sigma_prev = self._small(sigma_t), self._small(sigma_prev)
+        sigma_t_orig = sigma_t
         if refine_prior_sigma:
-            norm_x = row_sumsq_f64(xt).sqrt() / math.sqrt(self.dim)
+            norm_x = (row_sumsq_f64(xt).sqrt() / math.sqrt(self.dim)).view(B, 1, 1, 1)
             min_dist = torch.clamp(norm_x - self.norm_max, min=0)
-            sig_t = torch.minimum(torch.maximum(sig_t, min_dist), norm_x + self.norm_min)     # torch.clamp(min=, max=) order
+            max_dist = norm_x + self.norm_min
+            raw_sigma = torch.ones_like(norm_x) * sigma_t if self._is_scalar(sigma_t) else sigma_t
+            sigma_t = torch.minimum(torch.maximum(raw_sigma, min_dist), max_dist)      # torch.clamp(min=, max=) order
+            if self._is_scalar(sigma_prev):
+                sigma_prev = torch.ones_like(norm_x) * sigma_prev
         x32 = cast_f64_f32(xt)
         if "pred" in style:
             if self.sigma_model is None:
                 raise NlcError("style '%s' needs a sigma model (set_model)" % style)
-            c_in, c_noise, _, _ = self._scalars(sig_t)
+            c_in, c_noise, _, _ = self._scalars(self._per_sample(sigma_t, B))
             feat = self.model.run(x32, c_noise, mode="encode", in_scale=c_in, feat_nhwc=True)
-            r = self.sigma_model.run_nhwc(feat)                               # f32 [B]
-            dist_hat = sig_t * (1 + r)                                        # f64 * f32 -> f64, as in the reference
-            dist_prev_hat = dist_hat * (sig_p / sig_t)
-            sig_t = dist_hat
+            sigma_residual = self.sigma_model.run_nhwc(feat).view(B, 1, 1, 1)          # f32
+            dist_hat = sigma_t * (1 + sigma_residual)
+            dist_prev_hat = dist_hat * (sigma_prev / sigma_t)
+            sigma_t = dist_hat
             if style == "pred":
-                sig_p = dist_prev_hat
-        sig_div = sig_orig if style == "pred_sigma" else sig_t
-        sig_div = sig_div.contiguous()
+                sigma_prev = dist_prev_hat
+        if self._is_scalar(sigma_t_orig):
+            sigma_t_orig = sigma_t_orig.reshape(-1, 1, 1, 1)
+        if self._is_scalar(sigma_t):
+            sigma_t = sigma_t.reshape(-1, 1, 1, 1)
+        if self._is_scalar(sigma_prev):
+            sigma_prev = sigma_prev.reshape(-1, 1, 1, 1)
+        sig_div = self._per_sample(sigma_t_orig if style == "pred_sigma" else sigma_t, B)
         c_in, c_noise, c_skip, c_out = self._scalars(sig_div)
         F = self.model.run(x32, c_noise, mode="forward", in_scale=c_in)
         eps, den = torch.empty_like(xt), torch.empty_like(xt)
@@ -138,7 +162,7 @@ class EDMImageExperiment(ImageExperiment):
                                       sig_div.data_ptr(), eps.data_ptr(), den.data_ptr(), B, D, _s()), "nlc_edm_eps")
         if norm_eps:
             eps = self._normalize(eps)
-        return eps, den, sig_t.view(B, 1, 1, 1), sig_p.view(B, 1, 1, 1)
+        return eps, den, sigma_t, sigma_prev
 
     def _normalize(self, x):
         """utils.normalize on the f64 tensor (:841-842,908-909)."""
@@ -165,41 +189,41 @@ class EDMImageExperiment(ImageExperiment):
         else:
             raise NotImplementedError
         steps = torch.cat([torch.as_tensor(steps), torch.zeros_like(steps[:1])])          # host f64 schedule
+        steps_dev = steps.to(self.device)                                              # 0-dim views of it feed the sigma algebra
         one = torch.ones(B, device=self.device, dtype=torch.float64)
+        co = lambda v: self._per_sample(v, B)                                          # sigma-like -> [B] f64 kernel coefficients
         x_next = lincomb(latents.to(torch.float64).contiguous(), one * float(steps[0]))
         for i, (s_cur, s_next) in enumerate(zip(steps[:-1], steps[1:])):
             x_cur = x_next
-            s_cur, s_next0 = float(s_cur), float(s_next)
+            s_cur = float(s_cur)
+            sigma_next0 = steps_dev[i + 1]                                             # 0-dim f64, as in the reference
             gamma = min(self.S_churn / n, np.sqrt(2) - 1) if self.S_min <= s_cur <= self.S_max else 0
-            s_hat0 = s_cur + gamma * s_cur
+            sigma_hat0 = steps_dev[i] + gamma * steps_dev[i]
             # churn noise (:880): the reference draws randn_like on EVERY step from the global generator; with
             # S_churn > 0 the draw is kept on every step so the stream stays aligned when S_min/S_max gate gamma
             z = torch.randn(x_cur.shape, dtype=torch.float64) if self.S_churn > 0 else None
             if gamma > 0:
                 z = z.to(self.device)
-                x_hat = lincomb(x_cur, one, z, one * (math.sqrt(s_hat0 ** 2 - s_cur ** 2) * self.S_noise))
+                x_hat = lincomb(x_cur, one, z, co((sigma_hat0 ** 2 - steps_dev[i] ** 2).sqrt() * self.S_noise))
             else:
                 x_hat = x_cur                                                  # + 0 * randn_like: exact no-op
-            eps, _, s_hat, s_nxt = self.get_denoise_vector(x_hat, s_hat0, s_next0, style=style_t, norm_eps=norm_e,
-                                                           refine_prior_sigma=refine_prior_sigma)
-            s_hat, s_nxt = s_hat.view(B), s_nxt.view(B)
-            eps = lincomb(eps, s_hat / s_hat0)                                 # eps * (sigma_hat / sigma_hat0)  (:884)
+            eps, _, sigma_hat, sigma_next = self.get_denoise_vector(x_hat, sigma_hat0, sigma_next0, style=style_t, norm_eps=norm_e,
+                                                                    refine_prior_sigma=refine_prior_sigma)
+            eps = lincomb(eps, co(sigma_hat / sigma_hat0))                     # eps * (sigma_hat / sigma_hat0)  (:884)
             if "pred_partial" in style_t:
-                s_nxt = one * s_next0
+                sigma_next = sigma_next0
             if style_t == "pred_partial":
-                x_next = lincomb(x_hat, one, eps, s_nxt - s_hat0)
+                x_next = lincomb(x_hat, one, eps, co(sigma_next - sigma_hat0))
             else:
-                x_next = lincomb(x_hat, one, eps, s_nxt - s_hat)
+                x_next = lincomb(x_hat, one, eps, co(sigma_next - sigma_hat))
             if style_t == "pred_partial3":
-                s_hat = one * s_hat0
+                sigma_hat = sigma_hat0
             if i < n - 1 and use_second_order:
-                s_nxt_in = s_nxt
-                eps_next, _, s_nxt, _ = self.get_denoise_vector(x_next, s_nxt_in, s_nxt_in * 0, style=style_next,
-                                                                norm_eps=norm_e, refine_prior_sigma=refine_prior_sigma)
-                s_nxt = s_nxt.view(B)
-                eps_next = lincomb(eps_next, s_nxt / s_next0)                 # (:904)
+                eps_next, _, sigma_next, _ = self.get_denoise_vector(x_next, sigma_next, sigma_next * 0, style=style_next,
+                                                                     norm_eps=norm_e, refine_prior_sigma=refine_prior_sigma)
+                eps_next = lincomb(eps_next, co(sigma_next / sigma_next0))     # (:904)
                 if "pred_partial" in style_next:
-                    s_nxt = one * s_next0
+                    sigma_next = sigma_next0
                 new_eps = lincomb(eps, one * eps_ratio, eps_next, one * (1 - eps_ratio))
                 if norm_combine:
                     new_eps = self._normalize(new_eps)
@@ -210,7 +234,7 @@ class EDMImageExperiment(ImageExperiment):
                     check(_ext.load().nlc_row_cosine_f64(new_eps.data_ptr(), eps.data_ptr(), 1e-6, cs.data_ptr(), B,
                                                          new_eps.numel() // B, _s()), "nlc_row_cosine_f64")
                     new_eps = lincomb(new_eps, cs)
-                x_next = lincomb(x_hat, one, new_eps, s_nxt - s_hat)
+                x_next = lincomb(x_hat, one, new_eps, co(sigma_next - sigma_hat))
         return x_next
 
     @torch.no_grad()

@@ -458,6 +458,25 @@ class ExperimentDiffusion:
 
     check_nan = True
 
+    # ---- sigma-net training: the frozen-encoder half of one iteration -------------------------------
+    @torch.no_grad()
+    @ops.on_device
+    def sigma_training_batch(self, batch_x, t, new_noise, microbatch=16):
+        """What ``ImageExperiment.train`` computes per iteration BEFORE the sigma net sees anything
+        (src/experiments.py:665-681): the regression target  dist_real = ||new_noise|| / sqrt(dim)  (B,1,1,1), the noised
+        batch  noisy_x = scheduler.diffusion(batch_x, t, new_noise)  and the frozen eps model's features
+        ``feat = cat_i model.encode(noisy_x[i : i + microbatch], t[i : i + microbatch])`` (NCHW f32).  The sigma net's own
+        forward / backward / DDP exchange stay with the training framework (out of scope: SURVEY.md §8 f-4)."""
+        dev = self.device
+        batch_x = batch_x.to(dev, torch.float32).contiguous()
+        new_noise = new_noise.to(dev, torch.float32).contiguous()
+        t = torch.as_tensor(t).long().reshape(-1)
+        B = batch_x.shape[0]
+        dist_real = (ops.row_sumsq(new_noise).sqrt() / math.sqrt(self.dim)).view(B, *([1] * (batch_x.dim() - 1)))
+        noisy_x, _ = self.scheduler.diffusion(batch_x, t, new_noise)
+        feats = [self.model.encode(noisy_x[i:i + microbatch], t[i:i + microbatch]) for i in range(0, B, microbatch)]
+        return torch.cat(feats), dist_real, noisy_x
+
 
 class ImageExperiment(ExperimentDiffusion):
     """src/experiments.py:553-560 (sampling only; training of the sigma net is out of scope)."""

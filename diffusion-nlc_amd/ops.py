@@ -455,3 +455,17 @@ def scale_rows(x: torch.Tensor, scale: Optional[torch.Tensor], scalar: float = 1
     check(lib.nlc_scale_rows(x.data_ptr(), _ptr(scale), scalar, out.data_ptr(), B, x.numel() // B, _stream()),
           "nlc_scale_rows")
     return out
+
+
+def lincomb_rows(x: torch.Tensor, ca: torch.Tensor, y: Optional[torch.Tensor] = None, cb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = ca[b]*x[b] (+ cb[b]*y[b]) on f32 [B, ...] tensors; ca / cb: f32 [B] device tensors."""
+    lib = _ext.load()
+    _need(x, torch.float32, "lincomb_rows x")
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    if y is not None:
+        _need(y, torch.float32, "lincomb_rows y")
+    check(lib.nlc_lincomb_rows(x.data_ptr(), _need(ca, torch.float32, "lincomb_rows ca").data_ptr(), _ptr(y),
+                               None if cb is None else _need(cb, torch.float32, "lincomb_rows cb").data_ptr(), out.data_ptr(), B,
+                               x.numel() // B, _stream()), "nlc_lincomb_rows")
+    return out

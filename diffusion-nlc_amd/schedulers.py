@@ -182,11 +182,22 @@ class Scheduler:
         return self.sigma_to_t_interp(sigma) if self.continuous_t else self.sigma_to_t(sigma)
 
     def diffusion(self, x_0, t, noise=None):
-        """src/schedulers.py:323-329 (training-time forward process; plain torch, not on the sampling path)."""
+        """src/schedulers.py:323-329, the training-time forward process  x_n = x_0 sqrt(abar_t) + noise sqrt(1 - abar_t)
+        (nlc_lincomb_rows).  ``noise`` defaults to a host draw from the global CPU generator, uploaded (the reference
+        draws torch.randn_like on the device; host draws keep seeds reproducible against the CPU reference)."""
+        if not x_0.is_cuda:
+            raise NlcError("diffusion: tensors must live on the GPU (no CPU fallback)")
         if noise is None:
-            noise = torch.randn_like(x_0)
-        alpha = self.alphas_cumprod.to(x_0.device)[t].view((-1,) + (1,) * (x_0.dim() - 1))
-        return x_0 * alpha.sqrt() + noise * (1 - alpha).sqrt(), noise
+            noise = torch.randn(x_0.shape, dtype=torch.float32)
+        dev = x_0.device
+        x_0 = x_0.to(torch.float32).contiguous()
+        noise = noise.to(dev, torch.float32).contiguous()
+        alpha = self.alphas_cumprod[torch.as_tensor(t).cpu().long().reshape(-1)]             # host table lookup, [B] f32
+        if alpha.numel() == 1:
+            alpha = alpha.expand(x_0.shape[0])
+        with torch.cuda.device(dev):
+            x_n = ops.lincomb_rows(x_0, alpha.sqrt().to(dev).contiguous(), noise, (1 - alpha).sqrt().to(dev).contiguous())
+        return x_n, noise
 
     def set_timesteps_sigma(self, start, end, num_inference_steps, style="DDIM", scale=1, continuous_t=False):
         """src/schedulers.py:227-284"""

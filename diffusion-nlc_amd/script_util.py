@@ -6,6 +6,8 @@ HIP-backed networks of this package.
 """
 from __future__ import annotations
 
+NUM_CLASSES = 1000          # src/script_util.py:12
+
 
 def create_sigma_eps_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False,
                            class_cond=False, use_checkpoint=False, attention_resolutions="16", num_heads=1,
@@ -15,8 +17,6 @@ def create_sigma_eps_model(image_size, num_channels, num_res_blocks, channel_mul
     """src/script_util.py:136-206.  NB: like the reference, ``feat_layer`` in kwargs is ignored (ADM always
     encodes through the full middle block)."""
     from .unet_adm import SigmaModel, UNetModel
-    if class_cond:
-        raise NotImplementedError("class-conditional ADM is outside the sampling hot path (SURVEY.md §8)")
     if channel_mult == "":
         table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4), 32: (1, 2, 2, 2)}
         if image_size not in table:
@@ -28,7 +28,7 @@ def create_sigma_eps_model(image_size, num_channels, num_res_blocks, channel_mul
     eps_model = UNetModel(image_size=image_size, in_channels=3, model_channels=num_channels,
                           out_channels=(3 if not learn_sigma else 6), num_res_blocks=num_res_blocks,
                           attention_resolutions=attention_ds, dropout=dropout, channel_mult=channel_mult,
-                          num_classes=None, use_checkpoint=use_checkpoint, use_fp16=use_fp16, num_heads=num_heads,
+                          num_classes=(NUM_CLASSES if class_cond else None), use_checkpoint=use_checkpoint, use_fp16=use_fp16, num_heads=num_heads,
                           num_head_channels=num_head_channels, num_heads_upsample=num_heads_upsample,
                           use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
                           use_new_attention_order=use_new_attention_order)

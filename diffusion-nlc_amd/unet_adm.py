@@ -112,14 +112,16 @@ class _Attention:
 
 
 class UNetModel(HipModule):
-    """src/unet_adm.py:396-731 (unconditional; class-conditional ADM is not on the sampling path here)."""
+    """src/unet_adm.py:396-731, unconditional or class-conditional (``model(x, t, y)``: the label embedding row is added
+    to the timestep embedding, :479-480,652-654 - here in the epilogue of time_embed's second Linear)."""
 
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0.0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
                  use_checkpoint=False, use_fp16=False, num_heads=1, num_head_channels=-1, num_heads_upsample=-1,
                  use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False, feat_layer=1):
-        if dims != 2 or num_classes is not None:
-            raise NotImplementedError("HIP UNetModel: 2-D, unconditional only (SURVEY.md §8 scope)")
+        if dims != 2:
+            raise NotImplementedError("HIP UNetModel: 2-D only (SURVEY.md §8 scope)")
+        self.num_classes = num_classes
         self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
         self.out_channels, self.num_res_blocks = out_channels, num_res_blocks
         self.attention_resolutions = tuple(attention_resolutions)
@@ -191,6 +193,8 @@ class UNetModel(HipModule):
         blocks_in, mid, blocks_out, ch_last, E = self._layout()
         sb.linear("time_embed.0", E, mc)
         sb.linear("time_embed.2", E, E)
+        if self.num_classes is not None:
+            sb.add("label_emb.weight", (self.num_classes, E))          # nn.Embedding (src/unet_adm.py:479-480)
         for layers in blocks_in + [mid] + blocks_out:
             for kind, p, cin, cout, kw in layers:
                 if kind == "conv_in":
@@ -216,6 +220,7 @@ class UNetModel(HipModule):
         P.freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(device)
         P.te0 = pack(sd, "time_embed.0", torch.float32, device)
         P.te2 = pack(sd, "time_embed.2", torch.float32, device)
+        P.label = f32(sd["label_emb.weight"], device) if self.num_classes is not None else None
         bank = EmbBank()
 
         def make(layers):
@@ -243,11 +248,14 @@ class UNetModel(HipModule):
         return P
 
     # ---- execution -----------------------------------------------------------------------------
-    def _emb(self, P, t):
+    def _emb(self, P, t, y=None):
         temb = ops.timestep_embedding(t, P.freqs, sin_first=False)          # cos || sin
         sp = self.compute_dtype == torch.bfloat16                            # f32 GEMMs of a bf16 model may split K
         e = ops.conv2d(temb, P.te0, act=ACT_SILU, allow_split=sp)            # Linear -> SiLU
-        e = ops.conv2d(e, P.te2, act=ACT_SILU, allow_split=sp)               # Linear; every consumer starts with SiLU(emb)
+        # emb = time_embed(...) + label_emb(y) (src/unet_adm.py:650-654): the gathered embedding rows ride in the GEMM's
+        # per-image add; every consumer starts with SiLU(emb), applied here once
+        rows = None if y is None else P.label.index_select(0, y)
+        e = ops.conv2d(e, P.te2, emb=rows, act=ACT_SILU, allow_split=sp)
         return P.bank(e)
 
     @staticmethod
@@ -268,7 +276,7 @@ class UNetModel(HipModule):
         return h
 
     def run(self, x_nchw: torch.Tensor, t: torch.Tensor, mode: str = "forward", in_scale: Optional[torch.Tensor] = None,
-            feat_nhwc: bool = False):
+            feat_nhwc: bool = False, y: Optional[torch.Tensor] = None):
         """x_nchw: f32 [B,C,H,W] on the GPU; t: f32 [B].  in_scale[b] multiplies the input (convert_coordinate).
 
         mode 'forward' -> eps_out NCHW f32 ; 'encode' -> feat ; 'both' -> (out, feat).
@@ -276,8 +284,10 @@ class UNetModel(HipModule):
         """
         P = self.plan()
         dt = self.compute_dtype
+        if (y is not None) != (self.num_classes is not None):
+            raise AssertionError("must specify y if and only if the model is class-conditional")     # src/unet_adm.py:645-647
         with torch.cuda.device(self.device):
-            emb_all = self._emb(P, t)
+            emb_all = self._emb(P, t, y)
             hs = []
             h = None
             for layers in P.inp:
@@ -308,17 +318,24 @@ class UNetModel(HipModule):
             t = t.expand(x.shape[0]).contiguous()
         return x, t
 
+    def _labels(self, y, n):
+        if y is None:
+            return None
+        y = torch.as_tensor(y).to(device=self.device, dtype=torch.int64).reshape(-1).contiguous()
+        assert y.shape == (n,)                                               # src/unet_adm.py:653
+        return y
+
     def forward(self, x, timesteps, y=None):
-        assert y is None, "must specify y if and only if the model is class-conditional"
-        return self.run(*self._prep(x, timesteps), mode="forward")
+        x, t = self._prep(x, timesteps)
+        return self.run(x, t, mode="forward", y=self._labels(y, x.shape[0]))
 
     def encode(self, x, timesteps, y=None):
-        assert y is None
-        return self.run(*self._prep(x, timesteps), mode="encode")
+        x, t = self._prep(x, timesteps)
+        return self.run(x, t, mode="encode", y=self._labels(y, x.shape[0]))
 
     def forward_and_encode(self, x, timesteps, y=None):
-        assert y is None
-        return self.run(*self._prep(x, timesteps), mode="both")
+        x, t = self._prep(x, timesteps)
+        return self.run(x, t, mode="both", y=self._labels(y, x.shape[0]))
 
 
 class SigmaModel(HipModule):

@@ -304,6 +304,12 @@ int nlc_sched_step(const nlc_sched_desc* d, int* nan_flag, void* stream);
 int nlc_scale_rows(const float* x, const float* scale /*[B]*/, float scalar, float* out,
                    int B, int64_t D, void* stream);
 
+/* out[b,:] = ca[b]*x[b,:] + cb[b]*y[b,:]  (y, cb may both be NULL), products and sum rounded separately.  The training-time
+ * forward process  x_n = x_0 sqrt(abar_t) + noise sqrt(1 - abar_t)  (Scheduler.diffusion, src/schedulers.py:323-329) that
+ * feeds the frozen-encoder feature extraction of the sigma-net training loop (src/experiments.py:656-681). */
+int nlc_lincomb_rows(const float* x, const float* ca /*[B]*/, const float* y, const float* cb /*[B]*/, float* out,
+                     int B, int64_t D, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * EDM / Heun + NLC sampler state (src/experiments.py:777-918): the state and eps are FLOAT64,
  * the network runs in float32, exactly as in the reference (:860,872,789-802).

@@ -130,7 +130,7 @@ def _walk_input(cfg: AdmConfig):
             ds *= 2
 
 
-def unet(sd: SD, cfg: AdmConfig, x: torch.Tensor, timesteps: torch.Tensor, mode: str = "forward"):
+def unet(sd: SD, cfg: AdmConfig, x: torch.Tensor, timesteps: torch.Tensor, mode: str = "forward", y=None):
     """UNetModel.forward / encode / forward_and_encode (src/unet_adm.py:636-731).
 
     mode: 'forward' -> out ; 'encode' -> feat ; 'both' -> (out, feat)
@@ -140,6 +140,8 @@ def unet(sd: SD, cfg: AdmConfig, x: torch.Tensor, timesteps: torch.Tensor, mode:
     temb = timestep_embedding(timesteps, cfg.model_channels)
     emb = F.linear(temb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    if y is not None:                                   # class-conditional: + label_emb(y) (src/unet_adm.py:652-654)
+        emb = emb + F.embedding(y, sd["label_emb.weight"])
 
     hs = []
     h = x

@@ -79,6 +79,8 @@ SIMPLE_TINY = dict(ch=64, out_ch=3, ch_mult=[1, 2, 2], num_res_blocks=1, attn_re
 EDM_TINY = dict(img_resolution=32, in_channels=3, out_channels=3, augment_dim=9, model_channels=32, channel_mult=[2, 2, 2],
                 num_blocks=2, attn_resolutions=[16], dropout=0.0, sigma_block=2)
 SIGMA_OVERRIDES = {"final_mlp.weight": 0.1, "final_mlp.bias": 0.5}
+# class-conditional ADM (model(x, t, y), src/unet_adm.py:479-480,652-654): ADM_TINY_B + label embedding of NUM_CLASSES rows
+ADM_TINY_CC = dict(ADM_TINY_B, class_cond=True)
 
 
 def simple_namespace(c):
@@ -411,6 +413,33 @@ def gen_project(models):
          cfg=json.dumps(dict(rate=rate_c, recal=True, seed=seed, B=B, res=res, **vars(args))))
 
 
+@torch.no_grad()
+def gen_classcond():
+    """Adds the class-conditional tiny ADM: its state_dict spec goes INTO the existing specs.json (other entries untouched),
+    its outputs into net_adm_tiny_cc.npz."""
+    from src import script_util
+    eps, sig, fshape = script_util.create_sigma_eps_model(**ADM_TINY_CC)
+    eps.load_state_dict(fill_state_dict(eps.state_dict(), seed=0))
+    sig.load_state_dict(fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES))
+    eps.eval(); sig.eval()
+    specs = json.loads((HERE / "specs.json").read_text())
+    specs["adm_tiny_cc"] = dict(eps=spec_of(eps), sigma=spec_of(sig), feat_shape=list(fshape),
+                                eps_checksum=checksum(eps.state_dict()), sigma_checksum=checksum(sig.state_dict()))
+    specs["_configs"]["adm_tiny_cc"] = ADM_TINY_CC
+    (HERE / "specs.json").write_text(json.dumps(specs, indent=0))
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(3, 3, 32, 32, generator=g)
+    t = torch.tensor([17.5, 1000.0, 400.0])
+    y = torch.tensor([0, 999, 417])
+    out = eps(x, t, y)
+    feat = eps.encode(x, t, y)
+    out2, feat2 = eps.forward_and_encode(x, t, y)
+    assert torch.equal(out, out2) and torch.equal(feat, feat2)
+    out_other = eps(x, t, torch.tensor([5, 5, 5]))
+    assert (out - out_other).abs().max() > 1e-4                  # the label really conditions the output
+    save("net_adm_tiny_cc", x=x, t=t, y=y, out=out, feat=feat, r=sig(feat))
+
+
 def main():
     _stub_missing_modules()
     torch.manual_seed(0)
@@ -421,6 +450,7 @@ def main():
     gen_loops(models)
     gen_inpaint(models)
     gen_project(models)
+    gen_classcond()
 
 
 if __name__ == "__main__":

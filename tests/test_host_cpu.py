@@ -29,7 +29,7 @@ def build_product(tag):
     return script_util.create_edm_sigma_eps_model(**c)
 
 
-@pytest.mark.parametrize("tag", ["adm_tiny", "adm_tiny_b", "simple_tiny", "edm_tiny"])
+@pytest.mark.parametrize("tag", ["adm_tiny", "adm_tiny_b", "adm_tiny_cc", "simple_tiny", "edm_tiny"])
 def test_param_spec_matches_reference_state_dict(tag):
     """Key names, order, shapes and dtypes equal what the reference modules produced (tests/golden/specs.json)."""
     specs = load_specs()

@@ -53,6 +53,26 @@ def test_bf16_networks_track_reference(tag):
     assert e_out < 5e-2 * so and e_feat < 5e-2 * sf and e_r < 5e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_class_conditional_adm(dtype):
+    """model(x, t, y) (src/unet_adm.py:479-480,652-654): golden from the reference's class-conditional UNetModel."""
+    g = load_npz("net_adm_tiny_cc")
+    eps, sig = _models("adm_tiny_cc", dtype)
+    out = eps(g["x"], g["t"], g["y"]).cpu()
+    feat = eps.encode(g["x"], g["t"], g["y"]).cpu()
+    r = sig(feat).cpu()
+    tol_o, tol_f = (1e-3, 1e-3) if dtype == torch.float32 else (5e-2 * g["out"].abs().max().item(), 5e-2 * g["feat"].abs().max().item())
+    e_out, e_feat, e_r = max_err(out, g["out"]), max_err(feat, g["feat"]), max_err(r, g["r"])
+    print(f"adm_tiny_cc: L-inf out {e_out:.2e} feat {e_feat:.2e} r {e_r:.2e}")
+    assert e_out < tol_o and e_feat < tol_f and e_r < (1e-3 if dtype == torch.float32 else 5e-2)
+    o2, f2 = eps.forward_and_encode(g["x"], g["t"], g["y"])
+    assert torch.equal(o2.cpu(), out) and torch.equal(f2.cpu(), feat)
+    with pytest.raises(AssertionError):
+        eps(g["x"], g["t"])                                   # y is mandatory for a class-conditional model (:645-647)
+    other = eps(g["x"], g["t"], torch.zeros_like(g["y"])).cpu()
+    assert max_err(other, out) > 1e-4
+
+
 def test_batch_independence():
     """Samples do not couple inside a batch (the property the multi-GPU sharding relies on)."""
     g = load_npz("net_adm_tiny")
@@ -61,3 +81,31 @@ def test_batch_independence():
     for b in range(2):
         one = eps(g["x"][b:b + 1], g["t"][b:b + 1]).cpu()
         assert torch.equal(one[0], full[b])
+
+
+def test_sigma_training_batch_matches_the_reference_formulas():
+    """SURVEY.md §8 f-4 (src/experiments.py:665-681): forward process, regression target and the microbatched frozen-encoder
+    features of one sigma-net training iteration, against the reference's formulas on the CPU + the oracle's encoder."""
+    from diffusion_nlc_amd.experiments import ImageExperiment
+    from diffusion_nlc_amd.schedulers import get_sampler
+    from oracle.sched import get_sampler as oracle_sampler
+    eps, sig = _models("adm_tiny", torch.float32)
+    s = get_sampler("ddim", 1000, 10, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall")
+    s.to("cuda:0")
+    exp = ImageExperiment(eps, s, batch_size=5, data_shape=(3, 64, 64), seed=3, device="cuda:0")
+    exp.set_model(eps, sig, learn_epsvar=True)
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(5, 3, 64, 64, generator=g) * 2 - 1
+    t = torch.tensor([0, 999, 500, 17, 640])
+    noise = torch.randn(5, 3, 64, 64, generator=g) * 1.1
+    feat, dist_real, noisy = exp.sigma_training_batch(x, t, noise, microbatch=2)          # microbatches of 2, 2, 1
+    os_ = oracle_sampler("ddim", 1000, 10, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall")
+    alpha = os_.alphas_cumprod[t].view(-1, 1, 1, 1)
+    noisy_ref = x * alpha.sqrt() + noise * (1 - alpha).sqrt()                              # src/schedulers.py:327-328
+    assert torch.equal(noisy.cpu(), noisy_ref)                                             # bit-exact f32 algebra
+    dref = torch.linalg.vector_norm(noise, dim=(1, 2, 3), keepdim=True) / (3 * 64 * 64) ** 0.5
+    assert ((dist_real.cpu() - dref).abs() / dref).max() < 1e-6
+    _, enc_fn, _, _ = oracle_nets("adm_tiny")
+    with torch.no_grad():
+        feat_ref = enc_fn(noisy_ref, t.float())
+    assert feat.shape == feat_ref.shape and max_err(feat.cpu(), feat_ref) < 1e-3

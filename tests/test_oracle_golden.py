@@ -41,6 +41,21 @@ def test_nets_match_reference(tag):
             assert torch.equal(o2, out) and torch.equal(f2, feat)
 
 
+def test_class_conditional_adm_matches_reference():
+    """model(x, t, y): the label-embedding row is added to the timestep embedding (src/unet_adm.py:479-480,652-654)."""
+    from oracle import adm
+    from tests.util import load_specs
+    g = load_npz("net_adm_tiny_cc")
+    sd_e, sd_s = state_dicts("adm_tiny_cc")
+    ucfg, scfg, _ = adm.configs_from_factory(**load_specs()["_configs"]["adm_tiny_cc"])
+    with torch.no_grad():
+        out = adm.unet(sd_e, ucfg, g["x"], g["t"], "forward", y=g["y"])
+        feat = adm.unet(sd_e, ucfg, g["x"], g["t"], "encode", y=g["y"])
+        assert max_err(out, g["out"]) < 1e-5 and max_err(feat, g["feat"]) < 1e-5
+        assert max_err(adm.sigma_net(sd_s, scfg, feat), g["r"]) < 1e-5
+        assert max_err(adm.unet(sd_e, ucfg, g["x"], g["t"], "forward", y=torch.zeros_like(g["y"])), g["out"]) > 1e-4
+
+
 def test_scheduler_tables_and_lookups():
     from oracle.sched import get_sampler
     g = load_npz("sched")
