@@ -286,13 +286,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
                     for (int k = 0; k < 16; ++k) v[k] = gelu_erf(v[k]);
                 }
                 T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
-                *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
-                *reinterpret_cast<uint4*>(op + 8) = f32_to_chunk<T>(v + 8);
-                if (has_stats) {
+                const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
+                *reinterpret_cast<uint4*>(op) = pk0;
+                *reinterpret_cast<uint4*>(op + 8) = pk1;
+                if (has_stats) {         // of the STORED (bf16-rounded) values - what the GroupNorm that follows reads
+                    float sv[16];
+                    chunk_to_f32<T>(pk0, sv); chunk_to_f32<T>(pk1, sv + 8);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        gsum[0] += v[k]; gsq[0] = fmaf(v[k], v[k], gsq[0]);
-                        gsum[1] += v[8 + k]; gsq[1] = fmaf(v[8 + k], v[8 + k], gsq[1]);
+                        gsum[0] += sv[k]; gsq[0] = fmaf(sv[k], sv[k], gsq[0]);
+                        gsum[1] += sv[8 + k]; gsq[1] = fmaf(sv[8 + k], sv[8 + k], gsq[1]);
                     }
                 }
             }
@@ -418,8 +421,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
             if (p.stats) {
                 // GroupNorm statistics ride along here too (the 16x16 / 8x8 levels): two neighbouring threads hold one
                 // 8-channel chunk of one pixel; one partial per pixel (stats_P = Hout * Wout), dispatch: Cout % 8 == 0
-                float s1 = (r[0] + r[1]) + (r[2] + r[3]);
-                float s2 = fmaf(r[0], r[0], fmaf(r[1], r[1], fmaf(r[2], r[2], r[3] * r[3])));
+                float q[4];                            // the STORED (bf16-rounded) values, as everywhere else
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = bf16_to_f32(f32_to_bf16(r[k]));
+                float s1 = (q[0] + q[1]) + (q[2] + q[3]);
+                float s2 = fmaf(q[0], q[0], fmaf(q[1], q[1], fmaf(q[2], q[2], q[3] * q[3])));
                 s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, false));
                 s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0xB1, 0xf, 0xf, false));
                 if (((n >> 2) & 1) == 0) {

@@ -354,15 +354,18 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                         for (int k = 0; k < 16; ++k) v[k] = gelu_erf(v[k]);
                     }
                     T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
+                    const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
 #ifndef HALO_NO_STORE                                          /* timing diagnostics only (tools/halo_variant.sh) */
-                    *reinterpret_cast<uint4*>(op) = f32_to_chunk<T>(v);
-                    *reinterpret_cast<uint4*>(op + 8) = f32_to_chunk<T>(v + 8);
+                    *reinterpret_cast<uint4*>(op) = pk0;
+                    *reinterpret_cast<uint4*>(op + 8) = pk1;
 #endif
-                    if (has_stats) {     // of the f32 values: their bf16 rounding is zero-mean, 2^-9 relative per element
+                    if (has_stats) {     // of the STORED (bf16-rounded) values - what the GroupNorm that follows reads
+                        float sv[16];
+                        chunk_to_f32<T>(pk0, sv); chunk_to_f32<T>(pk1, sv + 8);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            gsum[0] += v[k]; gsq[0] = fmaf(v[k], v[k], gsq[0]);
-                            gsum[1] += v[8 + k]; gsq[1] = fmaf(v[8 + k], v[8 + k], gsq[1]);
+                            gsum[0] += sv[k]; gsq[0] = fmaf(sv[k], sv[k], gsq[0]);
+                            gsum[1] += sv[8 + k]; gsq[1] = fmaf(sv[8 + k], sv[8 + k], gsq[1]);
                         }
                     }
                 }

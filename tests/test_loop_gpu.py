@@ -212,11 +212,11 @@ def test_continuous_t_loop_matches_reference():
                                return_log=True, chunk_size=1, sigma_pred_threshold=960)
     e0, ex = max_err(logs[3][0], g["x0_first"]), max_err(x, g["x"])
     print(f"continuous-t loop: L-inf first x0 {e0:.2e}, final {ex:.2e}")
-    # With continuous t a 1-ulp difference in ||x|| moves t itself (slope d t / d sigma is 3 ... 1000), so already the
-    # first step sits at ~3e-4, and this random-weight net amplifies it over 10 steps: two GroupNorm kernels that
-    # differ by 1-2 ulp (both within rounding of the reference) land at 2.3e-4 and 1.6e-3 on the final sample.
-    # Gate: first step at the north-star 1e-3; the 10-step trajectory at 5e-3.
-    assert e0 < 1e-3 and ex < 5e-3
+    # With continuous t a 1-ulp difference in ||x|| moves t itself (slope d t / d sigma is 3 ... 1000) and this random-weight
+    # net amplifies it over 10 steps: the REFERENCE arithmetic run against itself with the initial state perturbed by +-1 ulp
+    # ends 3e-4 ... 1.1e-3 apart (tests/test_oracle_golden.py::test_continuous_t_trajectory_is_conditioned_at_the_1e_3_level).
+    # Gate: first step at the north-star 1e-3; the 10-step trajectory at 3e-3 (about 3x that conditioning floor).
+    assert e0 < 1e-3 and ex < 3e-3
 
 
 @pytest.mark.parametrize("name", ["proj_linear", "proj_discrete"])
@@ -240,7 +240,7 @@ def test_projection_loop_matches_reference(name):
     e0, ex = max_err(logs[3][0], g["x0_first"]), max_err(x, g["x"])
     print(f"{name}: L-inf first x0 {e0:.2e}, final {ex:.2e}; sigma trace rel {es:.2e}")
     # trajectory tolerance: see test_continuous_t_loop_matches_reference (the discrete-t fixture stays at ~2e-4)
-    assert e0 < 1e-3 and es < 1e-3 and ex < (5e-3 if name == "proj_linear" else 1e-3)
+    assert e0 < 1e-3 and es < 1e-3 and ex < (3e-3 if name == "proj_linear" else 1e-3)
     x2, _ = exp.projection_loop(shape=(2, 3, 32, 32), gen=exp.new_gen(), norm_eps=True, return_log=False, chunk_size=1,
                                 sigma_estimate_rate=c["rate"], sigma_pred_threshold=960, recal_sigma_prev=c["recal"], **kw)
     assert torch.equal(x, x2)

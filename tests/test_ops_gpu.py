@@ -317,7 +317,7 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
     ref_sum, ref_sq = chunks.sum(dim=(1, 3)), (chunks.double() ** 2).sum(dim=(1, 3))
     got = st.double().sum(dim=1).cpu()
     assert (got[..., 0] - ref_sum.double()).abs().max() < 1e-2 * ref_sum.abs().max().clamp(min=1.0)
-    # (the sums are taken over the f32 values just before their bf16 rounding - zero-mean, 2^-9 relative per element)
+    # (every emitter sums the STORED, bf16-rounded values; what is left is f32 summation order)
     assert ((got[..., 1] - ref_sq) / ref_sq).abs().max() < 5e-4
     # a second conv makes the skip source of a concatenated GroupNorm input; 384 channels / 32 groups = 12: not a
     # multiple of 8 -> falls back; 256 + 256 = 512 -> group size 16, fused
@@ -336,7 +336,7 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
     sts = getattr(ys, "_nlc_stats", None)
     assert sts is not None and sts.shape == (2, 64, 32, 2)
     chs = ys.float().cpu().view(2, 64, 32, 8)
-    ref_s = chs.double().sum(dim=(1, 3))              # 512 stored values per chunk; the kernel summed them before rounding
+    ref_s = chs.double().sum(dim=(1, 3))              # 512 stored values per chunk
     assert (sts.double().sum(1).cpu()[..., 0] - ref_s).abs().max() < 2e-3 * ref_s.abs().max()
     assert ((sts.double().sum(1).cpu()[..., 1] - (chs.double() ** 2).sum(dim=(1, 3))) / (chs.double() ** 2).sum(dim=(1, 3))).abs().max() < 2e-3
     cat = torch.cat([yf, y2.float().cpu()], dim=-1).permute(0, 3, 1, 2)

@@ -137,3 +137,36 @@ def test_edm_sampler_matches_reference(name):
                       use_second_order=c["second"])
     assert x.dtype == torch.float64
     assert max_err(x, g["x"]) < 1e-4, max_err(x, g["x"])
+
+
+def test_continuous_t_trajectory_is_conditioned_at_the_1e_3_level():
+    """How far does the REFERENCE arithmetic itself move when the initial state is perturbed by +-1 ulp per element?
+    With continuous t the refined sigma feeds t through an interpolation whose slope dt/dsigma is 3 ... 1000, so rounding-level
+    differences are amplified; measured here with the CPU oracle (bit-identical to the reference on this fixture): final-sample
+    L-inf 3e-4 ... 1.1e-3 over four sign patterns.  This is the floor any independent implementation of the same arithmetic
+    sits on - the GPU tests gate the continuous-t trajectories at 3e-3 (about 3x this floor) and everything that is not
+    chaotically amplified (first step, sigma traces, all discrete-t fixtures) at the north-star 1e-3."""
+    from oracle.loop import DiffusionOracle
+    from oracle.sched import get_sampler
+    g = load_npz("cont_linear")
+    eps_fn, enc_fn, sig_fn, _ = oracle_nets("simple_tiny")
+    kw = dict(sigma_style="Linear", start_sigma=100, end_sigma=0.01, sampler_var="fixedsmall", eta=0.0, continuous_t=True)
+
+    def run(xT):
+        s = get_sampler("ddim", 1000, 10, **kw)
+        o = DiffusionOracle(eps_fn, enc_fn, sig_fn, s, (3, 32, 32), learn_epsvar=False, norm_min=0.0, norm_max=54.63, clip_fn="clamp")
+        return o.denoise_loop((2, 3, 32, 32), style="pred", norm_eps=True, refine_prior_sigma=True, xT=xT, sigma_pred_threshold=960)
+
+    s0 = get_sampler("ddim", 1000, 10, **kw)
+    z = torch.randn((2, 3, 32, 32), generator=torch.manual_seed(1234))
+    xT = (z / (1 / (s0.sampling_sigmas[0] ** 2 + 1)).sqrt()).float()
+    x_ref = run(xT)
+    assert max_err(x_ref, g["x"]) < 1e-4
+    moved = []
+    for seed in range(4):
+        up = torch.rand(xT.shape, generator=torch.Generator().manual_seed(seed)) < 0.5
+        xp = torch.where(up, torch.nextafter(xT, torch.full_like(xT, float("inf"))), torch.nextafter(xT, torch.full_like(xT, float("-inf"))))
+        moved.append(max_err(run(xp), x_ref))
+    print("continuous-t: final-sample L-inf of the oracle against itself under +-1 ulp input noise:", " ".join(f"{v:.1e}" for v in moved))
+    assert max(moved) > 2e-4          # the amplification is real (if this ever drops, tighten the GPU gates accordingly)
+    assert max(moved) < 3e-3          # ... and bounded: the 3e-3 GPU gate is not vacuous
