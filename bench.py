@@ -360,6 +360,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay each network evaluation from a captured hipGraph")
+    ap.add_argument("--gn-fusion", action="store_true", help="A/B: GroupNorm in the 3x3 convs' LDS prologue instead of a separate pass")
     ap.add_argument("--tiny", action="store_true", help="64x64 debugging configuration (NOT the headline metric)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / sharding / gather plumbing only: no sampling (runs without a GPU under gloo); never a measurement")
@@ -368,7 +369,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))                      # before anything in this process touches the GPU
 
-    from diffusion_nlc_amd import shard
+    from diffusion_nlc_amd import ops, shard
+    ops.FUSE_GN_CONV = bool(args.gn_fusion)
     use_gpu = torch.cuda.is_available() and not (args.dry_run and os.environ.get("NLC_BENCH_FORCE_CPU"))
     if not use_gpu and not args.dry_run:
         raise SystemExit("bench.py measures the HIP path: it needs a GPU (only --dry-run runs without one)")

@@ -55,6 +55,8 @@ class ConvDesc(C.Structure):
         ("stats_out", C.c_void_p),
         ("stats_bytes", C.c_int64),
         ("policy", C.c_int32),
+        ("gn_coef", C.c_void_p),
+        ("gn_act", C.c_int32),
         ("tuning", C.c_int32),
     ]
 
@@ -96,6 +98,8 @@ SIGNATURES = {
     "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
+    "nlc_conv2d_prologue_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
+    "nlc_groupnorm_coef": (C.c_int, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "nlc_conv_first_stats_partials": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),
     "nlc_groupnorm_workspace_bytes": (C.c_int64, [_i, _i, _i, _i]),

@@ -39,7 +39,8 @@ constexpr int B_STAGE = BN * KB_BYTES;          // 16 KiB
 constexpr int NBST = 4;                         // weight stages (3 steps ahead)
 constexpr int NA = 6, NB = 2;                   // DMA wave-instructions per wave: per halo / per weight tile
 constexpr int SCRATCH = 8 * 8 * KB_BYTES;       // landing zone of the padding DMA instructions (8 KiB)
-constexpr int HALO_LDS = 2 * A_STAGE + NBST * B_STAGE + SCRATCH;   // 157,696 B
+constexpr int COEF_STAGE = 1024;                // GroupNorm prologue: (a, b) of 128 input channels = one DMA piece, per halo stage
+constexpr int HALO_LDS = 2 * A_STAGE + NBST * B_STAGE + SCRATCH + 2 * COEF_STAGE;   // 159,744 B
 
 template <typename T> struct MmaH;
 template <> struct MmaH<bf16_raw> {
@@ -111,7 +112,7 @@ __device__ unsigned long long g_halo_tile[8][4];   // per wave: s_memtime before
 #define ESTAMP(i) do {} while (0)
 #endif
 
-template <typename T>
+template <typename T, bool GN>
 __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = ElemTraits<T>::kPerChunk;
@@ -148,7 +149,15 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     const unsigned ldsB = lds0 + 2 * A_STAGE;
     const unsigned ldsScratch = ldsB + NBST * B_STAGE + wave * 8 * KB_BYTES;
+    const unsigned ldsCoef = ldsB + NBST * B_STAGE + SCRATCH;
     char* smemB = smem + 2 * A_STAGE;
+    const char* smemCoef = smemB + NBST * B_STAGE + SCRATCH;
+    // GroupNorm prologue (bf16 only): the normalisation (+FiLM) (+SiLU) that precedes this convolution in the network is applied
+    // to every landed halo row IN LDS, once per element, by the wave that DMA'd it - the separate apply pass over HBM
+    // (read + write of the whole activation) disappears.  Wave 1 additionally fetches the 64 (a, b) pairs of each channel
+    // block (one 1-KiB piece = 128 channels, the second half is the next block's) into a two-stage LDS table.
+    constexpr bool has_gn = GN && sizeof(T) == 2;    // a separate instantiation: the plain kernel keeps its register allocation
+    const bool coef_wave = has_gn && wave == 1;      // wave-uniform
     const int ncb = p.Cin_pad / KBE;
     const int nk = ncb * 9;
 
@@ -159,12 +168,16 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     //      multiply, source select and zero-page select used to cost ~175 issue cycles per DMA, 1000+ per halo).
     //      Source-side swizzle: R & 7 == lrow.
     const char* haddr[NA];
+    const char* cbase = nullptr;                     // coef_wave: the current image's coefficient rows (wave-uniform)
+    unsigned hvalid = 0;                             // bit j: halo row of instruction j lies inside the image (prologue rows only)
     const int hchunk = lslot ^ lrow;
     const int cbs1 = p.C0 / KBE;                     // first channel block of the second segment (dispatch: C0 % KBE == 0)
     const char* zero = reinterpret_cast<const char*>(g_zero_page_h);
     auto halo_addr = [&](const TileH& t, int seg) {
         const char* src = seg ? p.x1 : p.x0;
         const int C = seg ? p.C1 : p.C0;
+        hvalid = 0;
+        if (coef_wave) cbase = reinterpret_cast<const char*>(p.gn_coef) + ((int64_t)t.tb * p.Ctot * 2) * 4;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int R = (wave + 8 * j) * 8 + lrow;
@@ -177,6 +190,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
             const int64_t pixel = ((int64_t)t.tb * p.Hin + sy) * p.Win + sx;
             haddr[j] = ok ? src + (pixel * C + hchunk * PER) * ES : zero;
+            hvalid |= (ok ? 1u : 0u) << j;
         }
     };
     const int64_t wrow = (int64_t)9 * p.Cin_pad * ES;
@@ -192,6 +206,40 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             glds16h(haddr[j] + off, real ? base + j * 64 * KB_BYTES : ldsScratch);
         }
     };
+    // coefficient piece of GLOBAL channel block cb (over cat(x0, x1)) into coefficient stage `astage` (wave 1 only)
+    auto issue_coef = [&](int cb, int astage) {
+        unsigned voff;                               // lane * 16, recomputed here on purpose (as a loop invariant it was spilled)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(voff));
+        glds16h_s(voff, cbase + (int64_t)cb * (KBE * 8), ldsCoef + astage * COEF_STAGE);
+    };
+    // in-place normalisation of this lane's 16 bytes of own halo instruction j (8 channels hchunk*8.. of one pixel), in two
+    // parts so that the LDS read latency of the data hides under an MFMA cluster: xload() issues the read, xfinish() reads the
+    // coefficients, computes and writes back.  Out-of-image rows stay zero: the convolution pads the NORMALISED input.
+    auto xptr = [&](int astage, int j) { return smem + astage * A_STAGE + (wave * 8 + j * 64) * KB_BYTES + lane * 16; };
+    auto xload = [&](int astage, int j) -> uint4 {
+        if constexpr (has_gn) return *reinterpret_cast<const uint4*>(xptr(astage, j));
+        else return uint4{0, 0, 0, 0};
+    };
+    auto xfinish = [&](int astage, int j, const uint4& d) {
+        if constexpr (has_gn) {
+            if ((hvalid >> j) & 1u) {
+                const float* cf = reinterpret_cast<const float*>(smemCoef + astage * COEF_STAGE) + hchunk * 16;
+                const unsigned w[4] = {d.x, d.y, d.z, d.w};
+                unsigned o[4];
+                const bool silu = p.gn_act == NLC_ACT_SILU;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 ab = *reinterpret_cast<const float4*>(cf + q * 4);       // a0 b0 a1 b1
+                    float y0 = fmaf(__uint_as_float(w[q] << 16), ab.x, ab.y);
+                    float y1 = fmaf(__uint_as_float(w[q] & 0xffff0000u), ab.z, ab.w);
+                    if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
+                    o[q] = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
+                }
+                *reinterpret_cast<uint4*>(xptr(astage, j)) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    };
+    auto xform = [&](int astage, int j) { xfinish(astage, j, xload(astage, j)); };
     unsigned woff[NB];                               // per-lane byte offset of this lane's weight row + chunk (constant)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -220,12 +268,14 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // With the taps unrolled at compile time the k-loop then carries no address arithmetic beyond one
     // add of the stage base per read (measured: the runtime-tap version spent more VALU issue cycles on
     // addresses than the MFMAs took).
-    // Only the k-half 0 offsets are kept (18 + 1 registers): chunk (4 + fq) ^ r == (fq ^ r) ^ 4, so half 1 is "^ 64".
-    int aoff[6][3], boff;
+    // Only the k-half 0 offsets are kept: chunk (4 + fq) ^ r == (fq ^ r) ^ 4, so half 1 is "^ 64".
+    // Halo rows: row = a_lane + k with k = yy * 18 + s (yy = 0..5, s = 0..2) and a_lane = wm * 72 + fr, so row & 7 = (fr + k) & 7:
+    // the swizzle term takes only 8 values over the 18 shifts.  Eight registers aoffm[m] = a_lane * 128 + ((fq ^ ((fr + m) & 7)) << 4)
+    // and the compile-time constant k * 128 in the ds_read's immediate offset replace eighteen precomputed offsets (those, with the
+    // rest of the loop-invariant addresses, no longer fitted beside the GroupNorm prologue's temporaries).
+    int aoffm[8], boff;
 #pragma unroll
-    for (int yy = 0; yy < 6; ++yy)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) aoff[yy][s] = hoff(a_lane + yy * HALO + s, fq);
+    for (int m = 0; m < 8; ++m) aoffm[m] = a_lane * KB_BYTES + ((fq ^ ((fr + m) & 7)) << 4);
     boff = hoff(b_lane, fq);                         // + j*16 rows = + j*2048 bytes (same row & 7)
 
     // fragment sets (register double buffer)
@@ -238,7 +288,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + j * 16 * KB_BYTES);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + (aoff[i + r][s] ^ (kk * 64)));
+        for (int i = 0; i < 4; ++i) {
+            const int k = (i + r) * HALO + s;                                    // compile-time: i, r, s are
+            fa[i] = *reinterpret_cast<const uint4*>(As + (aoffm[k & 7] ^ (kk * 64)) + k * KB_BYTES);
+        }
     };
     // operands swapped: D[m = channel][n = pixel]; lane (fr, fq) holds pixel fr, channels fq*4 + reg of MFMA tile j
     auto mma16 = [&](const uint4 (&fa)[4], const uint4 (&fb)[4]) {
@@ -467,12 +520,18 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         init_acc(c0);
     }
     halo_addr(cur, 0);
+    if (coef_wave) issue_coef(0, 0);
     issue_A(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
     issue_B(cur.n0, 0, 0);
     issue_B(cur.n0, min(1, nk - 1), 1);
     issue_B(cur.n0, min(2, nk - 1), 2);
     dma_wait_h<NB>();                                // halo 0 + weights 0,1 landed (weights 2 may fly)
     __syncthreads();
+    if (has_gn) {                                    // first halo of the launch: normalise all six own instructions at once
+#pragma unroll
+        for (int j = 0; j < NA; ++j) xform(0, j);
+        __syncthreads();
+    }
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     load_frags(fa0, fb0, 0, 0, K0{}, K0{});
@@ -516,6 +575,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                             if constexpr (tap == 0) {
                                 if (last_cb) halo_addr(nxt, 0);
                                 else if (p.C1 > 0 && cb + 1 == cbs1) halo_addr(cur, 1);
+                                if (coef_wave) issue_coef(last_cb ? 0 : cb + 1, hs ^ 1);     // BEFORE the halo rows: retired first
                             }
                             issue_A(last_cb ? 0 : cb + 1, hs ^ 1, std::integral_constant<int, 2 * tap>{}, std::integral_constant<int, 2>{});
                         }
@@ -524,6 +584,20 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #ifdef HALO_STAMP
                 if (stamp_on) { __builtin_amdgcn_sched_barrier(0); stp[tap] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #endif
+                // GroupNorm prologue: halo instructions (2t, 2t+1) of the NEXT channel block were issued at tap t and retired by this
+                // wave's wait at tap t + 2 (the coefficient piece: tap 0 -> retired at tap 1, published by that step's barrier).
+                // They are normalised in place one per step at taps 3..7 (instruction j = tap - 3; the sixth, which only wave 0 has,
+                // also at tap 7): the data read is issued here, ahead of the first MFMA cluster, the arithmetic follows the DMA issue.
+                // The barriers of those steps publish the result before tap 8 prefetches the next block's first fragments.
+                constexpr bool xf_tap = has_gn && tap >= 3 && tap <= 7;
+                const bool xf_on = xf_tap && more;
+                uint4 xd0 = uint4{0, 0, 0, 0}, xd1 = uint4{0, 0, 0, 0};
+                if constexpr (xf_tap) {
+                    if (xf_on) {
+                        xd0 = xload(hs ^ 1, tap - 3);
+                        if constexpr (tap == 7) { if (wave == 0) xd1 = xload(hs ^ 1, 5); }
+                    }
+                }
                 STAMP(0);
                 // Each half: 8 fragment reads for a LATER cluster + 16 MFMAs.  The sched_group_barrier pattern makes the
                 // backend interleave them as [1 ds_read, 2 MFMA] x 8 instead of "all reads, then all MFMAs": an MFMA holds
@@ -542,6 +616,17 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // starts with matrix work that is already in registers, and the first-dispatched waves 0-3 (which run
                 // ahead of their SIMD partners by ~150 cycles after every barrier) issue while waves 4-7 still compute.
                 issue_dma();
+                if constexpr (xf_tap) {
+                    if (xf_on) {
+                        // hard scheduling fences: the block's LDS reads must not be drawn into the [1 ds_read, 2 MFMA] groups around
+                        // it (that interleave kept 60+ registers live and spilled INSIDE the k-loop; a spill reload is a vector-
+                        // memory load whose wait drains every DMA in flight)
+                        __builtin_amdgcn_sched_barrier(0);
+                        xfinish(hs ^ 1, tap - 3, xd0);
+                        if constexpr (tap == 7) { if (wave == 0) xfinish(hs ^ 1, 5, xd1); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 STAMP(1);
                 load_frags(fa0, fb0, nast, bnext, std::integral_constant<int, ntap>{}, K0{});   // next step's first half
                 mma16(fa1, fb1);
@@ -554,7 +639,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // retire weights kt+2; instructions younger than them may stay in flight:
                 // this step's weights kt+3 (NB) and the halo instructions issued at this step or the previous one
                 // (issue order per step: weights, then 2 halo instructions at taps 0-2)
-                if constexpr (tap == 0 || tap == 3) { if (more) dma_wait_h<NB + 2>(); else dma_wait_h<NB>(); }
+                if constexpr (tap == 0) {
+                    if (more) { if (coef_wave) dma_wait_h<NB + 3>(); else dma_wait_h<NB + 2>(); } else dma_wait_h<NB>();
+                }
+                else if constexpr (tap == 3) { if (more) dma_wait_h<NB + 2>(); else dma_wait_h<NB>(); }
                 else if constexpr (tap == 1 || tap == 2) { if (more) dma_wait_h<NB + 4>(); else dma_wait_h<NB>(); }
                 else dma_wait_h<NB>();
                 STAMP(6);
@@ -593,16 +681,16 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     dma_wait_h<0>();          // the redundant tail fetches
 }
 
-template <typename T>
+template <typename T, bool GN>
 int launch_halo(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
     const int slot = nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
     });
     const int ncu = once.ncu[slot];
     const int nblk = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT;
     const int grid = nblk < ncu ? nblk : ncu;        // one persistent workgroup per CU (154 KiB of LDS each)
-    hipLaunchKernelGGL((conv_halo_kernel<T>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
+    hipLaunchKernelGGL((conv_halo_kernel<T, GN>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(halo): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
@@ -637,6 +725,10 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     return forced || blocks >= 256;
 }
 
+int nlc_conv_halo_prologue_ok(const KParams& p, int dtype) {
+    return dtype == NLC_BF16 && halo_eligible(p, dtype, nullptr) ? 1 : 0;
+}
+
 // GroupNorm statistics ride along when the halo kernel runs in bf16 with NHWC output and whole 128-channel N-tiles
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
     if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
@@ -648,5 +740,6 @@ int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
 // nlc_conv_desc.policy: NLC_CONV_NO_HALO disables, NLC_CONV_FORCE_HALO forces (for eligible shapes) regardless of the tile count.
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!halo_eligible(p, dtype, nullptr)) return NLC_EUNSUPPORTED;
-    return dtype == NLC_BF16 ? launch_halo<bf16_raw>(p, stream) : launch_halo<float>(p, stream);
+    if (dtype == NLC_BF16) return p.gn_coef ? launch_halo<bf16_raw, true>(p, stream) : launch_halo<bf16_raw, false>(p, stream);
+    return launch_halo<float, false>(p, stream);
 }

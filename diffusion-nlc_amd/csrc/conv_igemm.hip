@@ -264,6 +264,14 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     return nlc_conv_fast_stats_partials(p, dtype);
 }
 
+extern "C" int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype) {
+    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
+    if (d->policy == NLC_CONV_GENERIC) return 0;
+    KParams p{};
+    geometry_only(d, p);
+    return nlc_conv_halo_prologue_ok(p, dtype);
+}
+
 extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(d != nullptr, "nlc_conv2d: null descriptor");
     NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv2d: bad dtype %d", dtype);
@@ -306,6 +314,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
     p.ksplit = 1; p.partial = nullptr;
     p.stats = nullptr; p.stats_P = 0;
+    p.gn_coef = d->gn_coef; p.gn_act = d->gn_act;
+    NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  policy NLC_CONV_GENERIC forces the latter (A/B runs).
     NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: bad policy %d", d->policy);
@@ -323,6 +333,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / 8) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
             p.stats = (float*)d->stats_out; p.stats_P = P;
         }
+        NLC_REQUIRE(!p.gn_coef || nlc_conv_halo_prologue_ok(p, dtype),
+                    "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue (ask nlc_conv2d_prologue_supported first)");
         int rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         if (!Pfast) { p.stats = nullptr; p.stats_P = 0; }
@@ -340,6 +352,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         if (rc != NLC_EUNSUPPORTED) return rc;
         p.ksplit = 1; p.partial = nullptr;
     }
+    NLC_REQUIRE(!p.gn_coef, "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue");
     if (dtype == NLC_BF16) return launch<bf16_raw>(p, (hipStream_t)stream);
     return launch<float>(p, (hipStream_t)stream);
 }

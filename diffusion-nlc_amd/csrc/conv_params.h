@@ -27,6 +27,7 @@ struct KParams {
     int stats_P;        //   chunk (sum, sum of squares) of the STORED (bf16-rounded) outputs, one partial per (patch, M-wave)
     int policy;         // NLC_CONV_* kernel-selection policy of this call (nlc_conv_desc.policy)
     int tuning;         // A/B switches (nlc_conv_desc.tuning)
+    const float* gn_coef; int gn_act;   // conv_halo (bf16) only: input = act(a x + b) applied in LDS (nlc_conv_desc.gn_coef)
 };
 
 // conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)
@@ -37,5 +38,7 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype);
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: partials per image the halo kernel would emit GroupNorm statistics with for this launch (0: it would not)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype);
+// conv_halo.hip: 1 if the halo kernel would take this launch AND can apply a GroupNorm prologue (bf16)
+int nlc_conv_halo_prologue_ok(const KParams& p, int dtype);
 // conv_halo.hip: 3x3 with the input halo resident in LDS; same return convention
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream);

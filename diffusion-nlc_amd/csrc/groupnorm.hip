@@ -288,9 +288,14 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const GNParams p, float
 // array [B][P][C_src/8][2] of (sum, sum of squares) per 8-channel chunk and partial.  One workgroup per (group, image)
 // adds the group's chunks over all partials in f64 in a fixed order (thread t takes partials t, t+256, ...; tree over
 // the threads) -> (mean, rstd) in the same stat[b][g] table gn_finalize writes.
+struct GNCoefOut {        // optional second product of gn_finalize_chunks_kernel: y = a[b][c] x + b[b][c] folded per channel
+    float* coef;          // [B][C][2] or NULL
+    const float* gamma; const float* beta; const float* scale; const float* shift; int ss_stride;
+};
 __global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __restrict__ s0, int P0, int C0,
                                                               const float* __restrict__ s1, int P1, int C1,
-                                                              int gs, int G, int HW, float eps, float* __restrict__ stat) {
+                                                              int gs, int G, int HW, float eps, float* __restrict__ stat,
+                                                              const GNCoefOut co) {
     __shared__ double red[2][NT];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int q0 = g * gs / 8, q1 = (g + 1) * gs / 8;           // chunk range of this group over cat(x0, x1)
@@ -312,13 +317,30 @@ __global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __r
         if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
         __syncthreads();
     }
-    if (tid == 0) {
-        const double N = (double)HW * gs;
-        const double mean = red[0][0] / N;
-        double var = red[1][0] / N - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stat[((int64_t)b * G + g) * 2 + 0] = (float)mean;
-        stat[((int64_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    const double N = (double)HW * gs;
+    const double mean_d = red[0][0] / N;
+    double var = red[1][0] / N - mean_d * mean_d;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (tid == 0 && stat) {
+        stat[((int64_t)b * G + g) * 2 + 0] = mean;
+        stat[((int64_t)b * G + g) * 2 + 1] = rstd;
+    }
+    if (co.coef) {
+        // the same a / b factorisation gn_apply_fast_kernel evaluates per thread, written once per (image, channel) for the
+        // convolution that applies the normalisation in its LDS prologue (nlc_conv_desc.gn_coef)
+        const int C = C0 + C1;
+        for (int j = tid; j < gs; j += NT) {
+            const int c = g * gs + j;
+            float a = rstd * (co.gamma ? co.gamma[c] : 1.f);
+            float bb = (co.beta ? co.beta[c] : 0.f) - mean * a;
+            if (co.scale) {
+                const float sc = 1.f + co.scale[(int64_t)b * co.ss_stride + c];
+                const float sh = co.shift[(int64_t)b * co.ss_stride + c];
+                a *= sc; bb = bb * sc + sh;
+            }
+            *reinterpret_cast<float2*>(co.coef + ((int64_t)b * C + c) * 2) = float2{a, bb};
+        }
     }
 }
 
@@ -503,8 +525,26 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     int ppb = p.ps * UNR * 4;
     while ((int64_t)cdiv(HW, ppb) * B > 8192) ppb *= 2;
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
-                       eps, stat);
+                       eps, stat, GNCoefOut{});
     hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb);
     NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
+    return NLC_OK;
+}
+
+extern "C" int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
+                                  const float* scale, const float* shift, int ss_stride, const float* stats0, int P0,
+                                  const float* stats1, int P1, float* coef, void* stream) {
+    NLC_REQUIRE(coef && stats0 && P0 > 0, "nlc_groupnorm_coef: null pointer");
+    NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm_coef: bad dims");
+    NLC_REQUIRE((C1 == 0) == (stats1 == nullptr) && (C1 == 0 || P1 > 0), "nlc_groupnorm_coef: stats1 / C1 mismatch");
+    const int C = C0 + C1;
+    NLC_REQUIRE(C % groups == 0 && (C / groups) % 8 == 0 && C0 % 8 == 0 && C1 % 8 == 0,
+                "nlc_groupnorm_coef: group size %d and C0=%d, C1=%d must be multiples of 8", C / groups, C0, C1);
+    NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_coef: scale/shift must come together");
+    NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_coef: ss_stride < C");
+    GNCoefOut co{coef, gamma, beta, scale, shift, ss_stride};
+    hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, (hipStream_t)stream, stats0, P0, C0, stats1, P1, C1,
+                       C / groups, groups, HW, eps, (float*)nullptr, co);
+    NLC_CHECK_LAUNCH("nlc_groupnorm_coef");
     return NLC_OK;
 }

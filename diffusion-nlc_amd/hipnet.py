@@ -242,6 +242,15 @@ class Norm:
         return ops.groupnorm(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, silu=silu, x1=x1,
                              scale=scale, shift=shift)
 
+    def then_conv(self, x, pw, *, silu: bool, x1=None, scale=None, shift=None, **conv_kw):
+        """conv(act(norm(cat(x, x1)))) - with the normalisation applied inside the convolution's LDS prologue when the launch
+        supports it and the statistics rode along with x (x1), else as the separate GroupNorm pass followed by the conv."""
+        if ops.FUSE_GN_CONV and ops.conv2d(x, pw, x1=x1, query_prologue=True, **{k: v for k, v in conv_kw.items() if k in ("stride", "pad", "out_hw", "upsample2x", "out_nchw_f32")}):
+            coef = ops.groupnorm_coef(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, x1=x1, scale=scale, shift=shift)
+            if coef is not None:
+                return ops.conv2d(x, pw, x1=x1, gn_coef=coef, gn_act=ACT_SILU if silu else ACT_NONE, **conv_kw)
+        return ops.conv2d(self(x, silu=silu, x1=x1, scale=scale, shift=shift), pw, **conv_kw)
+
 
 def pack(sd, p, dtype, device, **kw) -> ops.PackedConv:
     return ops.pack_conv(sd[p + ".weight"], sd.get(p + ".bias"), dtype, device, **kw)

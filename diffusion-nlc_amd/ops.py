@@ -138,12 +138,16 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
            pad: Optional[tuple] = None, out_hw: Optional[tuple] = None, upsample2x: bool = False,
            emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
            act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True,
-           emit_stats: bool = True, allow_split: bool = False) -> torch.Tensor:
+           emit_stats: bool = True, allow_split: bool = False, gn_coef: Optional[torch.Tensor] = None,
+           gn_act: int = ACT_NONE, query_prologue: bool = False):
     """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1).
     ``emit_stats``: let the epilogue also write the GroupNorm statistics of the output when the launch supports it
     (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass.
     ``allow_split``: an f32 GEMM may split K (bf16 ones always may); the f32 parity path leaves it off so that its
-    summation order never depends on the shape."""
+    summation order never depends on the shape.
+    ``gn_coef`` / ``gn_act``: the GroupNorm (+FiLM) (+SiLU) in front of this convolution, applied by the convolution itself
+    on its way through LDS (coefficients from ``groupnorm_coef``); ``query_prologue=True`` only asks whether this launch
+    could do that (returns bool, launches nothing)."""
     lib = _ext.load()
     dt = pw.dtype
     linear = x0.dim() == 2
@@ -189,6 +193,12 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
                  out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY], tuning=CONV_TUNING)
+    if query_prologue:
+        return bool(lib.nlc_conv2d_prologue_supported(C.byref(d), dtype_enum(dt)))
+    if gn_coef is not None:
+        if gn_coef.dtype != torch.float32 or not gn_coef.is_cuda or gn_coef.numel() < B * pw.Cin * 2 + 128:
+            raise ValueError("conv2d: gn_coef must be a CUDA f32 [B, Cin, 2] table with >= 512 bytes of slack (groupnorm_coef)")
+        d.gn_coef, d.gn_act = gn_coef.data_ptr(), gn_act
     stats = None
     if dt == torch.bfloat16 and emit_stats and not out_nchw_f32 and not linear:
         # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel
@@ -306,6 +316,43 @@ def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
                             _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(), ws.data_ptr(),
                             dtype_enum(dt), _stream()), "nlc_groupnorm")
     return out
+
+
+# networks: apply GroupNorm(+FiLM)+SiLU inside the consuming 3x3 convolution's LDS prologue when the launch supports it.
+# OFF by default: measured on MI355X (ADM-256, B=16) the prologue removes the 7 ms / step apply pass but costs the convolutions
+# 8.4 ms - every (16x16 patch x 128 cout) tile normalises its own halo, i.e. each input element NT x 1.27 = 2.5 ... 5 times, on
+# the same SIMD issue ports the MFMAs need: 5.89 vs 6.16 images/s (profiles/r02_summary.md).  Kept, tested, one switch away.
+FUSE_GN_CONV = False
+
+
+def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1: Optional[torch.Tensor] = None,
+                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Per-(image, channel) coefficients (a, b) of GroupNorm(+FiLM) over cat(x0, x1) from the statistics that rode along
+    with the producing convolutions - for conv2d(gn_coef=...).  None when they are not available (f32 models, inputs without
+    attached statistics, group sizes that 8-channel chunks cannot express): the caller then runs groupnorm()."""
+    lib = _ext.load()
+    if not FUSED_GN_STATS or x0.dtype != torch.bfloat16:
+        return None
+    B, C0 = x0.shape[0], x0.shape[-1]
+    C1 = 0 if x1 is None else x1.shape[-1]
+    Ctot = C0 + C1
+    if (Ctot // groups) % 8 or C0 % 8 or C1 % 8 or Ctot % groups:
+        return None
+    s0 = getattr(x0, "_nlc_stats", None)
+    s1 = getattr(x1, "_nlc_stats", None) if x1 is not None else None
+    if s0 is None or (x1 is not None and s1 is None):
+        return None
+    HW = x0.numel() // (B * C0)
+    ss_stride = 0
+    if scale is not None:
+        ss_stride = scale.stride(0)
+        if shift is None or shift.stride(0) != ss_stride or scale.stride(1) != 1 or shift.stride(1) != 1:
+            raise ValueError("groupnorm_coef: scale/shift must be row-strided f32 views sharing a row stride")
+    coef = torch.empty(B * Ctot * 2 + 128, device=x0.device, dtype=torch.float32)        # + 512 bytes: the consumer's DMA reads whole 1-KiB pieces
+    check(lib.nlc_groupnorm_coef(C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), ss_stride,
+                                 s0.data_ptr(), s0.shape[1], _ptr(s1), 0 if s1 is None else s1.shape[1], coef.data_ptr(),
+                                 _stream()), "nlc_groupnorm_coef")
+    return coef
 
 
 def attention(qkv: torch.Tensor, heads: int) -> torch.Tensor:

@@ -64,26 +64,23 @@ class _ResBlock:
             self.emb_off, _ = bank.add(sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"])
 
     def __call__(self, x, x1, emb_all):
-        h = self.n1(x, silu=True, x1=x1)                      # one tensor with C0+C1 channels
-        if self.down:                                          # AvgPool2d on both branches (:193-195)
-            h = ops.avgpool2x2(h)
-            x = ops.avgpool2x2(x)
         emb = None if self.emb_off is None else emb_all[:, self.emb_off:]
-        if self.scale_shift or emb is None:
-            h = ops.conv2d(h, self.c1, upsample2x=self.up)
-        else:
-            h = ops.conv2d(h, self.c1, upsample2x=self.up, emb=emb)            # h + emb_out (:254)
+        c1_emb = None if (self.scale_shift or emb is None) else emb                      # h + emb_out (:254)
+        if self.down:                                          # AvgPool2d on both branches (:193-195): norm, then pool, then conv
+            h = ops.avgpool2x2(self.n1(x, silu=True, x1=x1))
+            x = ops.avgpool2x2(x)
+            h = ops.conv2d(h, self.c1, emb=c1_emb)
+        else:                                                  # GroupNorm+SiLU applied inside the conv's LDS prologue when it can be
+            h = self.n1.then_conv(x, self.c1, silu=True, x1=x1, upsample2x=self.up, emb=c1_emb)
         if self.up:
             x = ops.upsample2x(x)
-        if self.scale_shift and emb is not None:
-            h = self.n2(h, silu=True, scale=emb[:, :self.cout], shift=emb[:, self.cout:2 * self.cout])
-        else:
-            h = self.n2(h, silu=True)
         if self.skip is not None:
             res = ops.conv2d(x, self.skip, x1=x1)
         else:
             res = x
-        return ops.conv2d(h, self.c2, res=res)
+        if self.scale_shift and emb is not None:
+            return self.n2.then_conv(h, self.c2, silu=True, scale=emb[:, :self.cout], shift=emb[:, self.cout:2 * self.cout], res=res)
+        return self.n2.then_conv(h, self.c2, silu=True, res=res)
 
 
 class _Attention:
@@ -304,8 +301,7 @@ class UNetModel(HipModule):
                 feat = h
             for layers in P.out:
                 h = self._run(layers, h, hs.pop(), emb_all)
-            h = P.out_norm(h, silu=True)
-            out = ops.conv2d(h, P.out_conv, out_nchw_f32=True)
+            out = P.out_norm.then_conv(h, P.out_conv, silu=True, out_nchw_f32=True)
             if mode == "forward":
                 return out
             return out, (feat if feat_nhwc else ops.nhwc_to_nchw_f32(feat))

@@ -116,6 +116,12 @@ typedef struct nlc_conv_desc {
                          /* partial; P = nlc_conv2d_stats_partials(desc, dtype) must be > 0 (bf16, NHWC, Cout % 128 == 0,    */
                          /* launches that take the LDS-halo kernel).  Consumed by nlc_groupnorm_prestats.                    */
     int32_t policy;      /* NLC_CONV_* (0 = AUTO); the three queries below honour it like nlc_conv2d does */
+    const float* gn_coef; /* optional (NULL = none): the GroupNorm (+FiLM) (+SiLU) that precedes this convolution in the reference */
+    int32_t gn_act;      /* (src/unet_adm.py:182-185,206-211,248-252) applied to the INPUT on its way through LDS instead of in a     */
+                         /* separate pass over HBM: logical input = act(a[b][c] * x + b[b][c]) inside the image, 0 in the padding;    */
+                         /* gn_coef = float [B][C0+C1][2] = (a, b) from nlc_groupnorm_coef, allocated with >= 512 bytes of slack      */
+                         /* behind it; gn_act = NLC_ACT_NONE | NLC_ACT_SILU.  Only launches for which                                 */
+                         /* nlc_conv2d_prologue_supported(desc, dtype) returns 1 take it (bf16, LDS-halo kernel).                     */
     int32_t tuning;      /* 0 in production.  Bit mask of kernel A/B switches for in-process timing experiments (tools/): */
                          /* results are identical for every value, only the schedule changes (see conv_halo.hip).          */
 } nlc_conv_desc;
@@ -127,6 +133,9 @@ int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
 int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype);
 /* partials per image (P) with which nlc_conv2d would fill stats_out for this descriptor; 0: it would not emit statistics */
 int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype);
+/* 1 if nlc_conv2d would apply desc.gn_coef / gn_act in its LDS prologue for this descriptor (geometry, dtype and policy decide;
+ * the gn_* fields themselves are not looked at), else 0: the caller then runs nlc_groupnorm(_prestats) as a separate pass */
+int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype);
 
 /* First-layer convolution for tiny Cin (<=4): reads the sampler state in the reference's
  * own layout (NCHW f32), applies the per-sample input scale c_in[b] (convert_coordinate,
@@ -164,6 +173,14 @@ int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B
                            const float* scale, const float* shift, int ss_stride,
                            int silu, void* out, void* workspace, int dtype,
                            const float* stats0, int P0, const float* stats1, int P1, void* stream);
+
+/* The per-(image, channel) coefficients of the same normalisation, for the convolution that applies it in its LDS prologue
+ * (nlc_conv_desc.gn_coef): coef[b][c] = (a, b) with  a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift,
+ * statistics from the producing convolutions' epilogues exactly as in nlc_groupnorm_prestats (same f64 fixed-order fold).
+ * coef: float [B][C0+C1][2] (+ >= 512 bytes of slack behind it for the consumer's DMA). */
+int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
+                       const float* scale, const float* shift, int ss_stride, const float* stats0, int P0,
+                       const float* stats1, int P1, float* coef, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-head softmax attention on token-major tensors (flash style, no TxT matrix in HBM).

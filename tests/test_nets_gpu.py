@@ -109,3 +109,22 @@ def test_sigma_training_batch_matches_the_reference_formulas():
     with torch.no_grad():
         feat_ref = enc_fn(noisy_ref, t.float())
     assert feat.shape == feat_ref.shape and max_err(feat.cpu(), feat_ref) < 1e-3
+
+
+def test_adm_network_with_groupnorm_in_the_conv_prologue():
+    """ops.FUSE_GN_CONV (off by default: measured slower, see ops.py): the whole tiny ADM forward with every eligible
+    GroupNorm+SiLU(+FiLM) applied inside the consuming convolution against the default separate-pass build."""
+    from diffusion_nlc_amd import ops
+    g = load_npz("net_adm_tiny")
+    eps, _ = _models("adm_tiny", torch.bfloat16)
+    was_f, was_p = ops.FUSE_GN_CONV, ops.CONV_POLICY
+    try:
+        ops.CONV_POLICY = "halo"                 # the tiny maps reach the halo kernel (and with it the prologue) only when forced
+        ops.FUSE_GN_CONV = False
+        ref = eps(g["x"], g["t"]).cpu()
+        ops.FUSE_GN_CONV = True
+        got = eps(g["x"], g["t"]).cpu()
+    finally:
+        ops.FUSE_GN_CONV, ops.CONV_POLICY = was_f, was_p
+    scale = ref.abs().max().item()
+    assert max_err(got, ref) <= 3e-2 * scale and max_err(got, g["out"]) <= 5e-2 * g["out"].abs().max().item()

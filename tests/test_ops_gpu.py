@@ -419,3 +419,101 @@ def test_pack_conv_weights_abi_matches_the_host_packing_rule():
         assert torch.equal(pw.bias.cpu(), (b[rp].double() * rs + ba).float())
     lin = ops.pack_conv(torch.randn(10, 20, generator=g), None, torch.float32, _dev())
     assert lin.bias is None and lin.KH == 1 and lin.Cin == 20
+
+
+GNCONV_CASES = [
+    dict(B=2, Cin=128, H=32, W=48, Cout=256, split=64, silu=True, res=True),          # concat input, edge + interior patches
+    dict(B=1, Cin=192, H=16, W=16, Cout=128, silu=False),                               # one patch per image: every halo side is padding
+    dict(B=2, Cin=64, H=16, W=32, Cout=128, silu=True, ups=True),                       # fused nearest-2x upsample of the normalised input
+    dict(B=1, Cin=128, H=256, W=256, Cout=256, silu=True, emb=True),                    # 512 tiles: two per persistent workgroup (cross-tile streams)
+    dict(B=3, Cin=256, H=32, W=32, Cout=6, silu=True, nchw=True),                       # the network's last layer (GroupNorm -> SiLU -> conv, 6 channels)
+]
+
+
+@pytest.mark.parametrize("case", GNCONV_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_with_groupnorm_prologue(case):
+    """nlc_conv_desc.gn_coef: conv(act(a[b][c] x + b[b][c])) with the per-(image, channel) affine map and SiLU applied to the
+    halo rows in LDS - against F.conv2d of the explicitly normalised input (zero padding AFTER the normalisation)."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    a_ = torch.rand(B, Cin, generator=g) + 0.5
+    b_ = torch.randn(B, Cin, generator=g) * 0.3
+    xr = _rt(x, torch.bfloat16)
+    y = xr * a_[:, :, None, None] + b_[:, :, None, None]
+    if case.get("silu"):
+        y = F.silu(y)
+    y = _rt(y, torch.bfloat16)                                       # the prologue stores bf16 back into LDS
+    if case.get("ups"):
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+    ref = F.conv2d(y, _rt(w, torch.bfloat16), b, padding=1)
+    emb = res = None
+    if case.get("emb"):
+        emb = torch.randn(B, Cout, generator=g)
+        ref = ref + emb[:, :, None, None]
+    if case.get("res"):
+        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + _rt(res, torch.bfloat16)
+    coef = torch.zeros(B * Cin * 2 + 128)
+    coef[:B * Cin * 2] = torch.stack([a_, b_], dim=-1).reshape(-1)
+    coef = coef.to(_dev())
+    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    split = case.get("split")
+    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
+    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "halo"
+    try:
+        kw = dict(x1=x1, upsample2x=bool(case.get("ups")), out_nchw_f32=bool(case.get("nchw")))
+        assert ops.conv2d(x0, pw, query_prologue=True, **kw)
+        got = ops.conv2d(x0, pw, gn_coef=coef, gn_act=1 if case.get("silu") else 0, emb=None if emb is None else emb.to(_dev()),
+                         res=None if res is None else _nhwc(res, torch.bfloat16), **kw)
+        torch.cuda.synchronize()
+        # a launch that cannot take the prologue must refuse the coefficients instead of ignoring them
+        ops.CONV_POLICY = "no_halo"
+        assert not ops.conv2d(x0, pw, query_prologue=True, **kw)
+        with pytest.raises(Exception):
+            ops.conv2d(x0, pw, gn_coef=coef, gn_act=1, **kw)
+    finally:
+        ops.CONV_POLICY = old
+    if not case.get("nchw"):
+        got = got.permute(0, 3, 1, 2)
+    _close(got, ref, 2e-2, "conv2d + GroupNorm prologue")
+
+
+def test_groupnorm_coef_then_conv_equals_groupnorm_then_conv():
+    """The network-level contract: Norm.then_conv (coefficients from the ride-along statistics + prologue) against the separate
+    GroupNorm pass followed by the plain convolution - same statistics, same arithmetic, so equal to bf16 rounding of the
+    normalised activation (one ulp where the two paths round a*x+b differently: fmaf vs mul+add)."""
+    from diffusion_nlc_amd import ops
+    from diffusion_nlc_amd.hipnet import Norm
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 128, 32, 32
+    x = torch.randn(B, 64, H, W, generator=g)
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "halo"
+    try:
+        w0 = torch.randn(C, 64, 3, 3, generator=g) / 24
+        h0 = ops.conv2d(_nhwc(x, torch.bfloat16), ops.pack_conv(w0, torch.zeros(C), torch.bfloat16, _dev()))      # carries statistics
+        h1 = ops.conv2d(_nhwc(x, torch.bfloat16), ops.pack_conv(w0.flip(0), torch.ones(C) * 0.3, torch.bfloat16, _dev()))
+        sd = {"n.weight": 1 + 0.2 * torch.randn(2 * C, generator=g), "n.bias": 0.1 * torch.randn(2 * C, generator=g)}
+        norm = Norm(sd, "n", _dev(), 32, 1e-5)
+        pw = ops.pack_conv(torch.randn(C, 2 * C, 3, 3, generator=g) / 48, torch.zeros(C), torch.bfloat16, _dev())
+        ss = (torch.randn(B, 4 * C, generator=g) * 0.3).to(_dev())
+        kw = dict(silu=True, x1=h1, scale=ss[:, :2 * C], shift=ss[:, 2 * C:])
+        was = ops.FUSE_GN_CONV
+        try:
+            ops.FUSE_GN_CONV = True
+            fused = norm.then_conv(h0, pw, **kw)
+            ops.FUSE_GN_CONV = False
+            plain = norm.then_conv(h0, pw, **kw)
+        finally:
+            ops.FUSE_GN_CONV = was
+    finally:
+        ops.CONV_POLICY = old
+    scale = plain.float().abs().max().item()
+    err = (fused.float() - plain.float()).abs().max().item()
+    assert getattr(fused, "_nlc_stats", None) is not None and err <= 1e-2 * scale, (err, scale)
