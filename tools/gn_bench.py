@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-silu", action="store_true", help="normalise only (memory-side rate of the same access pattern)")
+    ap.add_argument("--prestats", action="store_true", help="statistics 'ride along' (zeros attached): times finalize + apply only, 1 read + 1 write")
     args = ap.parse_args()
     global SILU
     SILU = not args.no_silu
@@ -36,6 +37,10 @@ def main():
         x0 = torch.randn(args.batch, H, H, c0, device=dev).to(dt)
         x1 = torch.randn(args.batch, H, H, c1, device=dev).to(dt) if c1 else None
         C = c0 + c1
+        if args.prestats:
+            x0._nlc_stats = torch.zeros(args.batch, (H // 16) ** 2 * 4 if H >= 16 else H * H, c0 // 8, 2, device=dev)
+            if x1 is not None:
+                x1._nlc_stats = torch.zeros(args.batch, x0._nlc_stats.shape[1], c1 // 8, 2, device=dev)
         g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
         for _ in range(3):
             ops.groupnorm(x0, g, b, groups=32, eps=1e-5, silu=SILU, x1=x1)
@@ -47,7 +52,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
-        nbytes = 3.0 * args.batch * H * H * C * x0.element_size()
+        nbytes = (2.0 if args.prestats else 3.0) * args.batch * H * H * C * x0.element_size()
         tot_ms += ms; tot_b += nbytes
         print(f"GN {C:5d}ch ({c0}+{c1}) @{H:3d}^2  {ms * 1e3:9.1f} us  {nbytes / ms / 1e6:8.0f} GB/s", flush=True)
     print(f"total {tot_ms:.2f} ms, {tot_b / tot_ms / 1e6:.0f} GB/s")
