@@ -99,6 +99,7 @@ __device__ unsigned long long g_halo_clock[4];     // {s_memtime, s_memrealtime}
 __device__ unsigned long long g_halo_stamps[8][8];
 __device__ unsigned long long g_halo_epi[8][6];    // inside the epilogue of tile 1: start, cadd loads issued, pixel loop done, stats done, acc re-initialised
 __device__ unsigned long long g_halo_steps[8][12];  // per wave: s_memtime at the start of each of the 9 taps of (tile 1, cb 1) + at the end of tap 8
+__device__ unsigned long long g_halo_cb[8][12];     // per wave: s_memtime at the start of every channel block of tile 1 (up to 10) + around its epilogue
 __device__ unsigned long long g_halo_tile[8][4];   // per wave: s_memtime before / after the epilogues of tiles 1 and 2 of workgroup 0
 #define STAMP(i) do { if (stamp_on && tap == HALO_STAMP_TAP) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define STAMP_FLUSH() do { if (stamp_on && tap == HALO_STAMP_TAP && lane == 0) { for (int q_ = 0; q_ < 8; ++q_) g_halo_stamps[wave][q_] = st[q_]; } } while (0)
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             const bool more = !last_cb || has_next;  // a halo follows this one in the stream
 #ifdef HALO_STAMP
             const bool stamp_on = blockIdx.x == 0 && tl == wi + gx && cb == 1;
+            if (blockIdx.x == 0 && tl == wi + gx && lane == 0 && cb < 10) { __builtin_amdgcn_sched_barrier(0); g_halo_cb[wave][cb] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
             unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             unsigned long long stp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -670,6 +672,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         epilogue(cur, nxt);                          // registers -> global, asynchronous stores; no LDS, no barrier
 #ifdef HALO_STAMP
         if (blockIdx.x == 0 && lane == 0 && (tix_ == 1 || tix_ == 2)) g_halo_tile[wave][(tix_ - 1) * 2 + 1] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 0 && lane == 0 && tix_ == 1) { g_halo_cb[wave][10] = g_halo_tile[wave][0]; g_halo_cb[wave][11] = g_halo_tile[wave][1]; }
 #endif
         if (!has_next) break;
         cur = nxt;
@@ -705,6 +708,7 @@ extern "C" int nlc_debug_halo_stamps(unsigned long long* out) {
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 68, HIP_SYMBOL(g_halo_tile), sizeof(unsigned long long) * 32);
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 100, HIP_SYMBOL(g_halo_epi), sizeof(unsigned long long) * 48);
     if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 148, HIP_SYMBOL(g_halo_steps), sizeof(unsigned long long) * 96);
+    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 244, HIP_SYMBOL(g_halo_cb), sizeof(unsigned long long) * 96);
     return rc;
 }
 #endif

@@ -25,7 +25,7 @@ while time.time() < t_end:
     torch.cuda.synchronize()
 torch.cuda.synchronize()
 lib = _ext.load()
-buf = (ctypes.c_ulonglong * 244)()
+buf = (ctypes.c_ulonglong * 340)()
 lib.nlc_debug_halo_stamps.argtypes = [ctypes.c_void_p]
 rc = lib.nlc_debug_halo_stamps(buf)
 st = [[buf[w_ * 8 + q] for q in range(8)] for w_ in range(8)]
@@ -48,6 +48,12 @@ print("k-step durations of (tile 1, channel block 1), cycles, taps 0..8, then th
 for w_ in range(8):
     d = [sp[w_][q + 1] - sp[w_][q] for q in range(9)]
     print(f"  wave {w_}: " + " ".join(f"{v:6d}" for v in d) + f"   sum {sum(d):7d}")
+cbs = [[buf[244 + w_ * 12 + q] for q in range(12)] for w_ in range(8)]
+ncb = cin // 64
+print("tile 1: cycles per channel block (start of cb c -> start of cb c+1; the last one -> start of the epilogue), then the epilogue:")
+for w_ in range(8):
+    t = cbs[w_][:ncb] + [cbs[w_][10]]
+    print(f"  wave {w_}: " + " ".join(f"{t[i + 1] - t[i]:7d}" for i in range(ncb)) + f"   epilogue {cbs[w_][11] - cbs[w_][10]:6d}")
 print("rc", rc, " (s_memtime ticks relative to the earliest wave's step start)")
 print("wave " + " ".join(f"{n:>14s}" for n in names))
 for w_ in range(8):
