@@ -6,14 +6,14 @@ root="$(cd "$here/../.." && pwd)"
 out="$here/../libnlc_hip.so"
 mkdir -p "$here/obj"
 pids=()
-for f in abi pack conv_igemm conv_fast conv_halo groupnorm attention elementwise sampler edm constraint; do
+for f in abi pack conv_igemm conv_fast conv_halo conv_wide groupnorm attention elementwise sampler edm constraint; do
   o="$here/obj/$f.o"
   if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/conv_params.h" -nt "$o" ] || [ "$root/include/nlc_hip.h" -nt "$o" ] || [ "$here/build.sh" -nt "$o" ]; then
     extra=""
     # the sampler kernels restate the reference's f32 algebra op by op: no FMA contraction there
     # (sqrt(s^2 - sqrt(s^2)^2) must be exactly 0, src/schedulers.py:445-446)
     if [ "$f" = "sampler" ] || [ "$f" = "edm" ]; then extra="-ffp-contract=off"; fi
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -I"$root/include" -I"$here" -c "$here/$f.hip" -o "$o" &
+    hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC $extra -I"$root/include" -I"$here" -c "$here/$f.hip" -o "$o" &
     pids+=($!)
   fi
 done

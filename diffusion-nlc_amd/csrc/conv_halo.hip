@@ -718,7 +718,7 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     // benchmark measures are chosen by the caller, launch by launch
     const bool forced = p.policy == NLC_CONV_FORCE_HALO;
     if (forced_out) *forced_out = forced;
-    if (p.policy == NLC_CONV_NO_HALO || p.policy == NLC_CONV_GENERIC) return false;
+    if (p.policy == NLC_CONV_NO_HALO || p.policy == NLC_CONV_GENERIC) return false;       // (FORCE_WIDE: production rules for the rest)
     if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1)) return false;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     if (p.Hout % PATCH || p.Wout % PATCH || p.Hout != HL || p.Wout != WL) return false;

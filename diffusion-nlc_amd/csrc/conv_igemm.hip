@@ -249,7 +249,8 @@ static void geometry_only(const nlc_conv_desc* d, KParams& p) {
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Cout = d->Cout;
     p.Cin_pad = d->Cin_pad; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.B = d->B;
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
-    p.ups = d->upsample2x ? 1 : 0; p.out_mode = d->out_mode; p.policy = d->policy;
+    p.ups = d->upsample2x ? 1 : 0; p.out_mode = d->out_mode; p.policy = d->policy; p.tuning = d->tuning;
+    p.act = d->act; p.bias = d->bias; p.emb = d->emb; p.emb_stride = d->emb_stride; p.gn_coef = d->gn_coef;    // kernel choice looks at these
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
 }
@@ -259,7 +260,9 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     if (d->policy == NLC_CONV_GENERIC) return 0;
     KParams p{};
     geometry_only(d, p);
-    const int P = nlc_conv_halo_stats_partials(p, dtype);
+    int P = nlc_conv_wide_stats_partials(p, dtype);
+    if (P > 0) return P;
+    P = nlc_conv_halo_stats_partials(p, dtype);
     if (P > 0) return P;
     return nlc_conv_fast_stats_partials(p, dtype);
 }
@@ -318,7 +321,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  policy NLC_CONV_GENERIC forces the latter (A/B runs).
-    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: bad policy %d", d->policy);
+    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_WIDE, "nlc_conv2d: bad policy %d", d->policy);
     p.policy = d->policy; p.tuning = d->tuning;
     const bool force_generic = d->policy == NLC_CONV_GENERIC;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
@@ -326,7 +329,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     if (!force_generic) {
         int Pfast = 0;
         if (d->stats_out) {
-            const int Phalo = nlc_conv_halo_stats_partials(p, dtype);
+            const int Pwide = nlc_conv_wide_stats_partials(p, dtype);
+            const int Phalo = Pwide > 0 ? Pwide : nlc_conv_halo_stats_partials(p, dtype);
             Pfast = Phalo > 0 ? 0 : nlc_conv_fast_stats_partials(p, dtype);
             const int P = Phalo > 0 ? Phalo : Pfast;
             NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
@@ -335,7 +339,9 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         }
         NLC_REQUIRE(!p.gn_coef || nlc_conv_halo_prologue_ok(p, dtype),
                     "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue (ask nlc_conv2d_prologue_supported first)");
-        int rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
+        int rc = nlc_conv_wide_dispatch(p, dtype, (hipStream_t)stream);
+        if (rc != NLC_EUNSUPPORTED) return rc;
+        rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         if (!Pfast) { p.stats = nullptr; p.stats_P = 0; }
         if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace

@@ -517,3 +517,56 @@ def test_groupnorm_coef_then_conv_equals_groupnorm_then_conv():
     scale = plain.float().abs().max().item()
     err = (fused.float() - plain.float()).abs().max().item()
     assert getattr(fused, "_nlc_stats", None) is not None and err <= 1e-2 * scale, (err, scale)
+
+
+WIDE_CASES = [
+    dict(B=2, Cin=128, H=16, W=32, Cout=128, split=64, emb=True, res=True, scale=math.sqrt(0.5)),       # one patch per image, concat input
+    dict(B=1, Cin=64, H=32, W=64, Cout=256, bias=False),                                                  # interior + border patches, 2 N-tiles
+    dict(B=2, Cin=64, H=8, W=16, Cout=128, ups=True, res=True),                                           # fused nearest-2x upsample
+    dict(B=3, Cin=192, H=16, W=64, Cout=128, emb=True),                                                   # 6 k-blocks (three loop trips)
+    dict(B=2, Cin=128, H=256, W=256, Cout=256, res=True),                                                 # 512 tiles: two per persistent workgroup
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_wide_kernel(case):
+    """conv_wide_kernel (512-pixel x 128-channel tiles, one wave per SIMD, 32-channel k-blocks, buffer-load halo DMA with
+    out-of-range zero fill) forced for shapes of every kind it takes, against F.conv2d; plus its ride-along statistics."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1 if case.get("bias", True) else None
+    xr = _rt(x, torch.bfloat16)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if case.get("ups") else xr
+    ref = F.conv2d(xin, _rt(w, torch.bfloat16), b, padding=1)
+    emb = res = None
+    if case.get("emb"):
+        emb = torch.randn(B, Cout + 8, generator=g)
+        ref = ref + emb[:, :Cout, None, None]
+    if case.get("res"):
+        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + _rt(res, torch.bfloat16)
+    ref = ref * case.get("scale", 1.0)
+    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    split = case.get("split")
+    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
+    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "wide"
+    try:
+        got = ops.conv2d(x0, pw, x1=x1, upsample2x=bool(case.get("ups")), emb=None if emb is None else emb.to(_dev())[:, :],
+                         res=None if res is None else _nhwc(res, torch.bfloat16), out_scale=case.get("scale", 1.0))
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_POLICY = old
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    st = getattr(got, "_nlc_stats", None)
+    assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 32) * 4, Cout // 8, 2), "the wide kernel did not take this launch"
+    _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (wide kernel)")
+    ch = got.float().cpu().view(B, Ho * Wo, Cout // 8, 8).double()
+    tot = st.double().sum(dim=1).cpu()
+    s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
+    assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
+    assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3
