@@ -186,7 +186,13 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const GNParams p) {
 }
 
 // ---- fast path: nslot == 1 ---------------------------------------------------------------------------------
-constexpr int UNR = 8;
+#ifndef GN_UNR
+#define GN_UNR 8
+#endif
+#ifndef GN_APPLY_MAXBLK
+#define GN_APPLY_MAXBLK 8192
+#endif
+constexpr int UNR = GN_UNR;          // tuning knobs of the diagnostic builds (tools/variant.sh)
 
 template <typename T>
 __global__ __launch_bounds__(NT) void gn_stats_fast_kernel(const GNParams p) {
@@ -477,7 +483,7 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
         float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
         // apply blocks: 4 unrolled trips of `ps` pixels each per thread, capped so the grid stays <= ~8k blocks
         int ppb = p.ps * UNR * 4;
-        while ((int64_t)cdiv(HW, ppb) * B > 8192) ppb *= 2;
+        while ((int64_t)cdiv(HW, ppb) * B > GN_APPLY_MAXBLK) ppb *= 2;
         const int nblk_a = cdiv(HW, ppb);
         const bool inline_fin = p.nblk <= 8;         // small maps: no finalize launch, the apply threads fold the partials
         if (inline_fin) stat = nullptr;
@@ -523,7 +529,7 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     hipStream_t st = (hipStream_t)stream;
     float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
     int ppb = p.ps * UNR * 4;
-    while ((int64_t)cdiv(HW, ppb) * B > 8192) ppb *= 2;
+    while ((int64_t)cdiv(HW, ppb) * B > GN_APPLY_MAXBLK) ppb *= 2;
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
                        eps, stat, GNCoefOut{});
     hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb);

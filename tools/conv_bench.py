@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--tuning", default="0", help="comma list of nlc_conv_desc.tuning values to A/B, interleaved in this one process")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a ResBlock)")
+    ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights: same instruction stream, least energy per MFMA "
+                    "(what the clock does to the rate: MI355X_MICROARCH.md 'DVFS give-back')")
     args = ap.parse_args()
     global SHAPES
     if args.only >= 0:
@@ -46,6 +48,8 @@ def main():
     for H, cin, cout, k, note in SHAPES:
         x = torch.randn(args.batch, H, H, cin, device=dev).to(dt)
         w = torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)
+        if args.zeros:
+            x.zero_(); w.zero_()
         pw = ops.pack_conv(w, torch.zeros(cout), dt, dev)
         ups = note.endswith("ups")
         Ho = 2 * H if ups else H
