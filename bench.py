@@ -360,6 +360,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay each network evaluation from a captured hipGraph")
+    ap.add_argument("--ops-flag", action="append", default=[], metavar="NAME=VALUE", help="A/B: set a module-level switch of diffusion_nlc_amd.ops")
     ap.add_argument("--gn-fusion", action="store_true", help="A/B: GroupNorm in the 3x3 convs' LDS prologue instead of a separate pass")
     ap.add_argument("--tiny", action="store_true", help="64x64 debugging configuration (NOT the headline metric)")
     ap.add_argument("--dry-run", action="store_true",
@@ -371,6 +372,11 @@ def main():
 
     from diffusion_nlc_amd import ops, shard
     ops.FUSE_GN_CONV = bool(args.gn_fusion)
+    for kv in args.ops_flag:                      # A/B switches of diffusion_nlc_amd.ops, e.g. --ops-flag FUSE_GN_POOL=0
+        k, v = kv.split("=", 1)
+        if not hasattr(ops, k):
+            raise SystemExit(f"bench.py: ops has no switch {k!r}")
+        setattr(ops, k, type(getattr(ops, k))(int(v)) if isinstance(getattr(ops, k), (bool, int)) else v)
     use_gpu = torch.cuda.is_available() and not (args.dry_run and os.environ.get("NLC_BENCH_FORCE_CPU"))
     if not use_gpu and not args.dry_run:
         raise SystemExit("bench.py measures the HIP path: it needs a GPU (only --dry-run runs without one)")

@@ -350,15 +350,11 @@ __global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __r
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_apply_fast_kernel(const GNParams p, const float* __restrict__ stat, int pix_per_blk) {
-    constexpr int PER = ElemTraits<T>::kPerChunk;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int active = p.tpp * p.ps;
-    if (tid >= active) return;
-    const int tx = tid % p.tpp, pl = tid / p.tpp;
-    const int c0 = tx * PER;
-    float ca[PER], cb[PER];
+// y = ca[j] * x + cb[j] for the PER channels from c0 of image b: GroupNorm (mean, rstd from `stat`, or folded here from the few
+// partials of a small map) x gamma / beta x FiLM (1 + scale, shift)
+template <int PER>
+__device__ __forceinline__ void gn_channel_coefs(const GNParams& p, const float* __restrict__ stat, int b, int c0,
+                                                 float (&ca)[PER], float (&cb)[PER]) {
     float mean = 0.f, rstd = 0.f;
     int gprev = -1;
 #pragma unroll
@@ -391,6 +387,18 @@ __global__ __launch_bounds__(NT) void gn_apply_fast_kernel(const GNParams p, con
         }
         ca[j] = a; cb[j] = bb;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_fast_kernel(const GNParams p, const float* __restrict__ stat, int pix_per_blk) {
+    constexpr int PER = ElemTraits<T>::kPerChunk;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int active = p.tpp * p.ps;
+    if (tid >= active) return;
+    const int tx = tid % p.tpp, pl = tid / p.tpp;
+    const int c0 = tx * PER;
+    float ca[PER], cb[PER];
+    gn_channel_coefs<PER>(p, stat, b, c0, ca, cb);
     const int pix0 = blockIdx.x * pix_per_blk;
     const int pix1 = min(pix0 + pix_per_blk, p.HW);
     T* outb = reinterpret_cast<T*>(p.out) + (int64_t)b * p.HW * p.C + c0;
@@ -422,6 +430,70 @@ __global__ __launch_bounds__(NT) void gn_apply_fast_kernel(const GNParams p, con
             f[j] = y;
         }
         *reinterpret_cast<uint4*>(outb + (int64_t)pix * p.C) = f32_to_chunk<T>(f);
+    }
+}
+
+// GroupNorm (+FiLM) (+SiLU) followed by AvgPool2d(2), and AvgPool2d(2) of the raw input beside it - the two branches of a
+// down-sampling ResBlock (src/unet_adm.py:193-195: h = in_rest(x); h = h_upd(h); x = x_upd(x)) from ONE read of x: the
+// full-resolution normalised tensor is never written.  Thread = (output pixel lane, 8/4-channel chunk); the four
+// activated values are averaged in f32 in the order avgpool_kernel uses ((a + b) + c + d) * 0.25, so the f32 path is
+// bit-identical to the two separate passes (the bf16 one skips an intermediate rounding).
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_pool_kernel(const GNParams p, const float* __restrict__ stat, int W, int opix_per_blk,
+                                                           T* __restrict__ out_x) {
+    constexpr int PER = ElemTraits<T>::kPerChunk;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int active = p.tpp * p.ps;
+    if (tid >= active) return;
+    const int tx = tid % p.tpp, pl = tid / p.tpp;
+    const int c0 = tx * PER;
+    float ca[PER], cb[PER];
+    gn_channel_coefs<PER>(p, stat, b, c0, ca, cb);
+    const int Wo = W >> 1, OHW = p.HW >> 2;
+    const int pix0 = blockIdx.x * opix_per_blk;
+    const int pix1 = min(pix0 + opix_per_blk, OHW);
+    const T* xb = reinterpret_cast<const T*>(p.x0) + (int64_t)b * p.HW * p.C + c0;
+    T* outb = reinterpret_cast<T*>(p.out) + (int64_t)b * OHW * p.C + c0;
+    T* outx = out_x + (int64_t)b * OHW * p.C + c0;
+    constexpr int U = 2;
+    auto one = [&](const uint4 (&v)[4], int opix) {
+        float hs[PER], xs[PER];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[PER];
+            chunk_to_f32<T>(v[k], f);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                float y = ca[j] * f[j] + cb[j];
+                if (p.silu) y = (sizeof(T) == 4) ? silu_exact(y) : silu_f(y);
+                if (k == 0) { hs[j] = y; xs[j] = f[j]; } else { hs[j] += y; xs[j] += f[j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { hs[j] *= 0.25f; xs[j] *= 0.25f; }
+        *reinterpret_cast<uint4*>(outb + (int64_t)opix * p.C) = f32_to_chunk<T>(hs);
+        *reinterpret_cast<uint4*>(outx + (int64_t)opix * p.C) = f32_to_chunk<T>(xs);
+    };
+    auto load4 = [&](uint4 (&v)[4], int opix) {
+        const int oy = opix / Wo, ox = opix - oy * Wo;
+        const T* p00 = xb + ((int64_t)(2 * oy) * W + 2 * ox) * p.C;
+        v[0] = *reinterpret_cast<const uint4*>(p00);
+        v[1] = *reinterpret_cast<const uint4*>(p00 + p.C);
+        v[2] = *reinterpret_cast<const uint4*>(p00 + (int64_t)W * p.C);
+        v[3] = *reinterpret_cast<const uint4*>(p00 + (int64_t)W * p.C + p.C);
+    };
+    int opix = pix0 + pl;
+    for (; opix + (U - 1) * p.ps < pix1; opix += U * p.ps) {
+        uint4 v[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load4(v[u], opix + u * p.ps);
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(v[u], opix + u * p.ps);
+    }
+    for (; opix < pix1; opix += p.ps) {
+        uint4 v[4];
+        load4(v, opix);
+        one(v, opix);
     }
 }
 
@@ -534,6 +606,49 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
                        eps, stat, GNCoefOut{});
     hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb);
     NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
+    return NLC_OK;
+}
+
+extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, int groups, float eps, const float* gamma,
+                                     const float* beta, const float* scale, const float* shift, int ss_stride, int silu,
+                                     void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0,
+                                     void* stream) {
+    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_groupnorm_pool2x2: bad dtype %d", dtype);
+    const int per = dtype == NLC_BF16 ? 8 : 4;
+    NLC_REQUIRE(x && out_norm && out_x && workspace, "nlc_groupnorm_pool2x2: null pointer");
+    NLC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && groups > 0 && H % 2 == 0 && W % 2 == 0, "nlc_groupnorm_pool2x2: bad dims (H, W even)");
+    NLC_REQUIRE(C % per == 0 && C % groups == 0, "nlc_groupnorm_pool2x2: C=%d must be a multiple of %d and of groups=%d", C, per, groups);
+    NLC_REQUIRE(C / per <= NT, "nlc_groupnorm_pool2x2: C=%d too large for the one-chunk-per-thread kernels", C);
+    NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_pool2x2: scale/shift must come together");
+    NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_pool2x2: ss_stride < C");
+    NLC_REQUIRE(!stats0 || (dtype == NLC_BF16 && P0 > 0 && (C / groups) % 8 == 0),
+                "nlc_groupnorm_pool2x2: ride-along statistics are bf16 only, group size a multiple of 8");
+    const int HW = H * W;
+    GNParams p;
+    fill_params(p, x, nullptr, C, 0, B, HW, groups, dtype);
+    p.eps = eps; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
+    p.silu = silu; p.out = (char*)out_norm; p.ws = (double*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
+    if (stats0) {
+        hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
+                           groups, HW, eps, stat, GNCoefOut{});
+    } else {
+        const size_t lds_stats = (size_t)p.ps * p.C * 3 * sizeof(float);
+        NLC_REQUIRE(lds_stats <= 64 * 1024, "nlc_groupnorm_pool2x2: LDS budget exceeded (C=%d)", C);
+        if (dtype == NLC_BF16) hipLaunchKernelGGL(gn_stats_fast_kernel<bf16_raw>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
+        else hipLaunchKernelGGL(gn_stats_fast_kernel<float>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
+        if (p.nblk <= 8) stat = nullptr;             // small maps: the apply threads fold the partials themselves
+        else hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
+    }
+    const int OHW = HW / 4;
+    int oppb = p.ps * 2 * 4;                         // 4 unrolled trips of 2 x ps output pixels (= 8 x ps input pixels)
+    while ((int64_t)cdiv(OHW, oppb) * B > GN_APPLY_MAXBLK) oppb *= 2;
+    if (dtype == NLC_BF16)
+        hipLaunchKernelGGL(gn_apply_pool_kernel<bf16_raw>, dim3(cdiv(OHW, oppb), B), dim3(NT), 0, st, p, stat, W, oppb, (bf16_raw*)out_x);
+    else
+        hipLaunchKernelGGL(gn_apply_pool_kernel<float>, dim3(cdiv(OHW, oppb), B), dim3(NT), 0, st, p, stat, W, oppb, (float*)out_x);
+    NLC_CHECK_LAUNCH("nlc_groupnorm_pool2x2");
     return NLC_OK;
 }
 

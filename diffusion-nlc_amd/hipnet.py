@@ -242,6 +242,12 @@ class Norm:
         return ops.groupnorm(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, silu=silu, x1=x1,
                              scale=scale, shift=shift)
 
+    def pooled(self, x, silu: bool):
+        """(avgpool2x2(act(norm(x))), avgpool2x2(x)): both branches of a down-sampling ResBlock from one read of x."""
+        if ops.groupnorm_pool2x2_supported(x):
+            return ops.groupnorm_pool2x2(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, silu=silu)
+        return ops.avgpool2x2(self(x, silu=silu)), ops.avgpool2x2(x)
+
     def then_conv(self, x, pw, *, silu: bool, x1=None, scale=None, shift=None, **conv_kw):
         """conv(act(norm(cat(x, x1)))) - with the normalisation applied inside the convolution's LDS prologue when the launch
         supports it and the statistics rode along with x (x1), else as the separate GroupNorm pass followed by the conv."""

@@ -318,6 +318,44 @@ def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
     return out
 
 
+def groupnorm_pool2x2(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], *, groups: int, eps: float,
+                      silu: bool, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None):
+    """(avgpool2x2(act(GroupNorm(x))), avgpool2x2(x)) on [B,H,W,C] from one read of x - the two branches of a down-sampling
+    ResBlock (src/unet_adm.py:193-195); the full-resolution normalised tensor is never written."""
+    lib = _ext.load()
+    dt = x.dtype
+    _need(x, dt, "groupnorm_pool2x2 x")
+    if x.dim() != 4:
+        raise ValueError("groupnorm_pool2x2: x must be [B,H,W,C]")
+    B, H, W, Cc = x.shape
+    out_h = torch.empty(B, H // 2, W // 2, Cc, device=x.device, dtype=dt)
+    out_x = torch.empty_like(out_h)
+    ss_stride = 0
+    if scale is not None:
+        for nm, v in (("scale", scale), ("shift", shift)):
+            if v is None or v.dtype != torch.float32 or not v.is_cuda or v.dim() != 2 or v.stride(1) != 1 or v.shape[1] < Cc:
+                raise ValueError(f"groupnorm_pool2x2: {nm} must be a CUDA f32 [B, >=C] view with unit inner stride")
+        ss_stride = scale.stride(0)
+        if shift.stride(0) != ss_stride:
+            raise ValueError("groupnorm_pool2x2: scale/shift must share a row stride")
+    ws = _gn_workspace(x.device, lib.nlc_groupnorm_workspace_bytes(B, H * W, Cc, groups))
+    s0 = None
+    if FUSED_GN_STATS and dt == torch.bfloat16 and (Cc // groups) % 8 == 0:
+        s0 = getattr(x, "_nlc_stats", None)
+    check(lib.nlc_groupnorm_pool2x2(x.data_ptr(), Cc, B, H, W, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift),
+                                    ss_stride, 1 if silu else 0, out_h.data_ptr(), out_x.data_ptr(), ws.data_ptr(), dtype_enum(dt),
+                                    _ptr(s0), 0 if s0 is None else s0.shape[1], _stream()), "nlc_groupnorm_pool2x2")
+    return out_h, out_x
+
+
+FUSE_GN_POOL = True        # networks: down-sampling ResBlocks use groupnorm_pool2x2 (A/B switch)
+
+
+def groupnorm_pool2x2_supported(x: torch.Tensor) -> bool:
+    per = 8 if x.dtype == torch.bfloat16 else 4
+    return FUSE_GN_POOL and x.dim() == 4 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % per == 0 and x.shape[3] // per <= 256
+
+
 # networks: apply GroupNorm(+FiLM)+SiLU inside the consuming 3x3 convolution's LDS prologue when the launch supports it.
 # OFF by default: measured on MI355X (ADM-256, B=16) the prologue removes the 7 ms / step apply pass but costs the convolutions
 # 8.4 ms - every (16x16 patch x 128 cout) tile normalises its own halo, i.e. each input element NT x 1.27 = 2.5 ... 5 times, on

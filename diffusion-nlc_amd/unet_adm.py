@@ -67,8 +67,9 @@ class _ResBlock:
         emb = None if self.emb_off is None else emb_all[:, self.emb_off:]
         c1_emb = None if (self.scale_shift or emb is None) else emb                      # h + emb_out (:254)
         if self.down:                                          # AvgPool2d on both branches (:193-195): norm, then pool, then conv
-            h = ops.avgpool2x2(self.n1(x, silu=True, x1=x1))
-            x = ops.avgpool2x2(x)
+            if x1 is not None:
+                raise NotImplementedError("down-sampling ResBlock on a concatenated input (the reference has none)")
+            h, x = self.n1.pooled(x, silu=True)                # one read of x for both branches, no full-resolution h
             h = ops.conv2d(h, self.c1, emb=c1_emb)
         else:                                                  # GroupNorm+SiLU applied inside the conv's LDS prologue when it can be
             h = self.n1.then_conv(x, self.c1, silu=True, x1=x1, upsample2x=self.up, emb=c1_emb)

@@ -177,6 +177,15 @@ int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B
                            int silu, void* out, void* workspace, int dtype,
                            const float* stats0, int P0, const float* stats1, int P1, void* stream);
 
+/* The two branches of a down-sampling ResBlock from ONE read of x (src/unet_adm.py:193-195: h = in_rest(x); h = h_upd(h);
+ * x = x_upd(x), both AvgPool2d(2)):  out_norm = avgpool2x2(act(GroupNorm(x) (FiLM))),  out_x = avgpool2x2(x), both
+ * [B][H/2][W/2][C]; the full-resolution normalised tensor is never written.  Statistics: stats0 / P0 as in
+ * nlc_groupnorm_prestats (bf16), or NULL / 0 -> computed here by a pass over x.  f32: bit-identical to nlc_groupnorm followed by
+ * nlc_avgpool2x2; bf16: the pooled mean is taken of the f32 activations (one rounding less).  Same workspace as nlc_groupnorm. */
+int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, int groups, float eps, const float* gamma,
+                          const float* beta, const float* scale, const float* shift, int ss_stride, int silu,
+                          void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0, void* stream);
+
 /* The per-(image, channel) coefficients of the same normalisation, for the convolution that applies it in its LDS prologue
  * (nlc_conv_desc.gn_coef): coef[b][c] = (a, b) with  a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift,
  * statistics from the producing convolutions' epilogues exactly as in nlc_groupnorm_prestats (same f64 fixed-order fold).

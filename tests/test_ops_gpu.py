@@ -182,6 +182,75 @@ def test_groupnorm(case, dtype):
     _close(got.permute(0, 2, 1), ref, _tol(dtype) * (1 if dtype == torch.float32 else 1.5), "groupnorm")
 
 
+GNPOOL_CASES = [
+    dict(B=2, C=64, H=8, W=8, G=32, silu=True),
+    dict(B=2, C=256, H=32, W=32, G=32, silu=True),               # > 8 statistics blocks: the finalize launch
+    dict(B=1, C=512, H=16, W=48, G=32, silu=True, film=True),    # ragged map, FiLM
+    dict(B=3, C=32, H=2, W=2, G=8, silu=False),                  # one output pixel
+    dict(B=1, C=1024, H=16, W=16, G=32, silu=True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", GNPOOL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_groupnorm_pool2x2(case, dtype):
+    """nlc_groupnorm_pool2x2 = (AvgPool2d(2)(act(GroupNorm(x))), AvgPool2d(2)(x)) - both branches of a down-sampling ResBlock
+    (src/unet_adm.py:193-195) - against torch, and against the two separate passes it replaces (f32: bit-identical)."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(23)
+    B, Cc, H, W, G = case["B"], case["C"], case["H"], case["W"], case["G"]
+    x = torch.randn(B, Cc, H, W, generator=g) * 1.7 + 0.3
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    beta = 0.1 * torch.randn(Cc, generator=g)
+    xr = _rt(x, dtype)
+    ref = F.group_norm(xr, G, gamma, beta, 1e-5)
+    scale = shift = None
+    if case.get("film"):
+        ss = torch.randn(B, 2 * Cc, generator=g) * 0.3
+        ref = ref * (1 + ss[:, :Cc, None, None]) + ss[:, Cc:, None, None]
+        ss_d = ss.to(_dev())
+        scale, shift = ss_d[:, :Cc], ss_d[:, Cc:]
+    if case.get("silu"):
+        ref = F.silu(ref)
+    ref_h, ref_x = F.avg_pool2d(ref, 2), F.avg_pool2d(xr, 2)
+    xd = _nhwc(x, dtype)
+    gd, bd = gamma.to(_dev()), beta.to(_dev())
+    got_h, got_x = ops.groupnorm_pool2x2(xd, gd, bd, groups=G, eps=1e-5, silu=bool(case.get("silu")), scale=scale, shift=shift)
+    tol = _tol(dtype) * (1 if dtype == torch.float32 else 1.5)
+    _close(got_h.permute(0, 3, 1, 2), ref_h, tol, "groupnorm_pool2x2 h")
+    _close(got_x.permute(0, 3, 1, 2), ref_x, tol, "groupnorm_pool2x2 x")
+    sep_h = ops.avgpool2x2(ops.groupnorm(xd, gd, bd, groups=G, eps=1e-5, silu=bool(case.get("silu")), scale=scale, shift=shift))
+    sep_x = ops.avgpool2x2(xd)
+    assert torch.equal(got_x, sep_x)
+    if dtype == torch.float32:
+        assert torch.equal(got_h, sep_h)
+    else:
+        assert (got_h.float() - sep_h.float()).abs().max().item() <= 2e-2 * ref_h.abs().max().item()
+
+
+def test_groupnorm_pool2x2_with_ride_along_statistics():
+    """bf16 production route: the statistics come from the producing convolution's epilogue (halo kernel, 256 tiles)."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(29)
+    B, Cin, H, W, Cout = 16, 64, 32, 32, 256
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    y = ops.conv2d(_nhwc(x, torch.bfloat16), ops.pack_conv(w, torch.zeros(Cout), torch.bfloat16, _dev()))
+    assert getattr(y, "_nlc_stats", None) is not None
+    gamma, beta = torch.randn(Cout, generator=g).to(_dev()), torch.randn(Cout, generator=g).to(_dev())
+    h, xp = ops.groupnorm_pool2x2(y, gamma, beta, groups=32, eps=1e-5, silu=True)
+    yf = y.float().cpu().permute(0, 3, 1, 2)
+    ref_h = F.avg_pool2d(F.silu(F.group_norm(yf, 32, gamma.cpu(), beta.cpu(), eps=1e-5)), 2)
+    _close(h.permute(0, 3, 1, 2), ref_h, 1.5e-2, "groupnorm_pool2x2 (ride-along statistics) h")
+    _close(xp.permute(0, 3, 1, 2), F.avg_pool2d(yf, 2), 1e-2, "groupnorm_pool2x2 (ride-along statistics) x")
+    ops.FUSED_GN_STATS = False
+    try:
+        h2, _ = ops.groupnorm_pool2x2(y, gamma, beta, groups=32, eps=1e-5, silu=True)
+    finally:
+        ops.FUSED_GN_STATS = True
+    assert (h.float() - h2.float()).abs().max().item() <= 2e-2 * ref_h.abs().max().item()
+
+
 ATTN_CASES = [
     dict(B=2, T=64, H=2, D=32), dict(B=1, T=256, H=4, D=64), dict(B=2, T=100, H=1, D=64),
     dict(B=2, T=4, H=2, D=64), dict(B=1, T=1024, H=2, D=64), dict(B=1, T=80, H=1, D=128),
