@@ -71,8 +71,13 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 
-template <typename T, int TAPS>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p) {
+template <int N> __device__ __forceinline__ void dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// STAGES = 2: two workgroups per CU hide each other's DMA latency (the many-tile launches).  STAGES = 3 / 4: one workgroup per
+// CU with the DMA of 2 / 3 k-steps in flight behind a counted wait - for the launches with at most one workgroup per CU
+// (attention projections, the 8x8 / 16x16 levels), where a k-step otherwise costs a full memory round trip.
+template <typename T, int TAPS, int STAGES>
+__global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = ElemTraits<T>::kPerChunk;
     constexpr int KBE = Mma<T>::KBE;
@@ -179,25 +184,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_fast_kernel(const KParams p)
         }
     };
 
-    // ---- main loop: k-step (cb, tap), taps innermost and unrolled.  Per step: issue the DMA of the
-    //      next step into the other stage, compute this stage, wait for the own DMA, barrier.
-    //      WAR safety: the stage being refilled was last read in the previous step, whose trailing
-    //      barrier every wave has passed.
-    stage_step(0, cb0, std::integral_constant<int, 0>{});
-    dma_wait_all();
+    // ---- main loop: k-step (cb, tap), taps innermost and unrolled.  Per step: issue the DMA of the step STAGES - 1 ahead into
+    //      the stage that was read in the previous step (every wave has passed that step's trailing barrier), compute this
+    //      stage, wait until the NEXT step's DMA has landed (8 wave-instructions per step and wave, in issue order: all but the
+    //      newest 8 (STAGES - 2) may stay in flight; the last steps of a tile simply drain), barrier.
+    constexpr int AHEAD = STAGES - 1;
+    const int nsteps = (cb1 - cb0) * TAPS;
+    auto issue_ahead = [&](int stage, int cb, auto tap_c, auto d_c) {       // step (cb, tap) + d
+        constexpr int t2 = decltype(tap_c)::value + decltype(d_c)::value;
+        stage_step(stage, cb + t2 / TAPS, std::integral_constant<int, t2 % TAPS>{});
+    };
+    // prologue: steps 0 .. AHEAD-1
+    [&]<int... d>(std::integer_sequence<int, d...>) {
+        ((d < nsteps ? issue_ahead(d, cb0, std::integral_constant<int, 0>{}, std::integral_constant<int, d>{}) : (void)0), ...);
+    }(std::make_integer_sequence<int, AHEAD>{});
+    if (nsteps >= AHEAD) dma_wait_n<8 * (AHEAD - 1)>(); else dma_wait_all();
     __syncthreads();
-    int kt = 0;
+    int kt = 0, cur = 0;
     for (int cb = cb0; cb < cb1; ++cb) {
-        const bool last_cb = cb + 1 == cb1;
         auto body = [&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
-            const int cur = kt & 1;
-            if constexpr (tap + 1 < TAPS) stage_step(cur ^ 1, cb, std::integral_constant<int, tap + 1>{});
-            else { if (!last_cb) stage_step(cur ^ 1, cb + 1, std::integral_constant<int, 0>{}); }
+            int nst = cur + AHEAD; if (nst >= STAGES) nst -= STAGES;
+            const bool more = kt + AHEAD < nsteps;               // workgroup-uniform
+            if (more) issue_ahead(nst, cb, tap_c, std::integral_constant<int, AHEAD>{});
             compute(cur);
-            dma_wait_all();
+            if constexpr (STAGES == 2) dma_wait_all();
+            else { if (more) dma_wait_n<8 * (AHEAD - 1)>(); else dma_wait_all(); }
             __syncthreads();
             ++kt;
+            if (++cur == STAGES) cur = 0;
         };
         body(std::integral_constant<int, 0>{});
         if constexpr (TAPS == 9) {
@@ -442,13 +457,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
     }
 }
 
-template <typename T, int TAPS>
+template <typename T, int TAPS, int STAGES>
 int launch_fast(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  STAGES * STAGE_BYTES);
     });
-    hipLaunchKernelGGL((conv_fast_kernel<T, TAPS>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_fast_kernel<T, TAPS, STAGES>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), STAGES * STAGE_BYTES, stream, p);
     if (p.ksplit > 1) {
         const int64_t quads = (int64_t)p.M * (p.Cout >> 2);
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, stream, p);
@@ -487,6 +503,14 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     return s < 2 ? 1 : s;
 }
 
+// Pipeline depth (bf16): tuning bits 1-2 pin it for A/B runs (2 -> 3 stages, 4 -> 4 stages, 6 -> 2 stages)
+int nlc_conv_fast_stages(const KParams& p) {
+    const int pin = p.tuning & 6;
+    if (pin == 2) return 3;
+    if (pin == 4) return 4;
+    return 2;
+}
+
 // GroupNorm statistics ride along on the fast path when the N-tiles are whole and the output is bf16 NHWC: from the conv
 // epilogue if every 128-pixel tile lies inside one image, from the split-K reduce kernel when K is split
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
@@ -501,6 +525,11 @@ int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!fast_shape(p)) return NLC_EUNSUPPORTED;
     const bool k3 = p.KH == 3;
-    if (dtype == NLC_BF16) return k3 ? launch_fast<bf16_raw, 9>(p, stream) : launch_fast<bf16_raw, 1>(p, stream);
-    return k3 ? launch_fast<float, 9>(p, stream) : launch_fast<float, 1>(p, stream);
+    if (dtype == NLC_BF16) {
+        const int st = nlc_conv_fast_stages(p);
+        if (st == 4) return k3 ? launch_fast<bf16_raw, 9, 4>(p, stream) : launch_fast<bf16_raw, 1, 4>(p, stream);
+        if (st == 3) return k3 ? launch_fast<bf16_raw, 9, 3>(p, stream) : launch_fast<bf16_raw, 1, 3>(p, stream);
+        return k3 ? launch_fast<bf16_raw, 9, 2>(p, stream) : launch_fast<bf16_raw, 1, 2>(p, stream);
+    }
+    return k3 ? launch_fast<float, 9, 2>(p, stream) : launch_fast<float, 1, 2>(p, stream);
 }

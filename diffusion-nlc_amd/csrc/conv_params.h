@@ -34,6 +34,7 @@ struct KParams {
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);
 // split-K policy for the shapes conv_fast takes (few output tiles, long K): number of splits, 1 = none
 int nlc_conv_fast_ksplit(const KParams& p, int dtype);
+int nlc_conv_fast_stages(const KParams& p);
 // conv_fast.hip: same for the fast path (0 when K would be split or a tile could straddle two images)
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: partials per image the halo kernel would emit GroupNorm statistics with for this launch (0: it would not)

@@ -517,6 +517,18 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
 
 }  // namespace
 
+// Pixels per apply workgroup: `unit` (= ps x unroll x 4 trips) for the big maps, capped so the grid stays <= GN_APPLY_MAXBLK
+// workgroups; halved down to `ps` (one chunk per thread) while the launch would have fewer than 512 workgroups - the 8x8 ... 32x32
+// levels otherwise ran 16 ... 128 workgroups of four dependent trips each on a 256-CU chip (12-15 us per launch instead of ~5).
+static int apply_pix_per_block(int HW, int B, int ps, int unit) {
+    int ppb = unit;
+    while ((int64_t)cdiv(HW, ppb) * B > GN_APPLY_MAXBLK) ppb *= 2;
+#ifndef GN_NO_SMALL_GRID                            // diagnostic build: the fixed unit, for A/B runs (tools/variant.sh)
+    while (ppb > ps && (int64_t)cdiv(HW, ppb) * B < 512) ppb /= 2;
+#endif
+    return ppb;
+}
+
 extern "C" int64_t nlc_groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
     (void)HW; (void)C;
     return (int64_t)B * MAX_NBLK * groups * 3 * sizeof(double) + (int64_t)B * groups * 2 * sizeof(float);
@@ -554,8 +566,7 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
     if (p.nslot == 1 && fast_ok) {
         float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
         // apply blocks: 4 unrolled trips of `ps` pixels each per thread, capped so the grid stays <= ~8k blocks
-        int ppb = p.ps * UNR * 4;
-        while ((int64_t)cdiv(HW, ppb) * B > GN_APPLY_MAXBLK) ppb *= 2;
+        const int ppb = apply_pix_per_block(HW, B, p.ps, p.ps * UNR * 4);
         const int nblk_a = cdiv(HW, ppb);
         const bool inline_fin = p.nblk <= 8;         // small maps: no finalize launch, the apply threads fold the partials
         if (inline_fin) stat = nullptr;
@@ -600,8 +611,7 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     p.silu = silu; p.out = (char*)out; p.ws = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
     float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
-    int ppb = p.ps * UNR * 4;
-    while ((int64_t)cdiv(HW, ppb) * B > GN_APPLY_MAXBLK) ppb *= 2;
+    const int ppb = apply_pix_per_block(HW, B, p.ps, p.ps * UNR * 4);
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
                        eps, stat, GNCoefOut{});
     hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb);
@@ -642,8 +652,7 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
         else hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
     }
     const int OHW = HW / 4;
-    int oppb = p.ps * 2 * 4;                         // 4 unrolled trips of 2 x ps output pixels (= 8 x ps input pixels)
-    while ((int64_t)cdiv(OHW, oppb) * B > GN_APPLY_MAXBLK) oppb *= 2;
+    const int oppb = apply_pix_per_block(OHW, B, p.ps, p.ps * 2 * 4);      // 4 unrolled trips of 2 x ps output pixels (= 8 x ps input pixels)
     if (dtype == NLC_BF16)
         hipLaunchKernelGGL(gn_apply_pool_kernel<bf16_raw>, dim3(cdiv(OHW, oppb), B), dim3(NT), 0, st, p, stat, W, oppb, (bf16_raw*)out_x);
     else

@@ -25,6 +25,11 @@ SHAPES = [  # (H, Cin, Cout, k, note); a trailing "ups" in the note = fused near
     (32, 512, 1536, 1, "qkv 512->1536 @32^2"),
     (128, 256, 256, 3, "256->256 @128^2->256^2 ups"),
     (64, 512, 512, 3, "512->512 @64^2->128^2 ups"),
+    (8, 1024, 3072, 1, "qkv 1024->3072 @8^2"),
+    (8, 1024, 1024, 1, "proj 1024->1024 @8^2"),
+    (16, 1024, 3072, 1, "qkv 1024->3072 @16^2"),
+    (16, 1024, 1024, 1, "proj 1024->1024 @16^2"),
+    (256, 256, 6, 3, "out 256->6 @256^2"),
 ]
 
 
