@@ -726,7 +726,9 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     if (p.C0 % kbe || p.C1 % kbe || p.Cin_pad / kbe > 128) return false;
     if ((int64_t)p.B * p.Hout * p.Wout >= (1ll << 31)) return false;
     const int blocks = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT;
-    return forced || blocks >= 256;
+    // >= 128 tiles: at 128-255 (the 16x16 level of ADM-256 at B = 16) half the CUs idle, and the kernel still beats conv_fast +
+    // split-K + reduce (1024->1024: 100 vs 114 us, 512->1024: 55 vs 70, 256->1024: 34 vs 52; 2048->1024 level)
+    return forced || blocks >= 128;
 }
 
 int nlc_conv_halo_prologue_ok(const KParams& p, int dtype) {

@@ -46,7 +46,7 @@ enum {
 enum { NLC_CLIP_NONE = 0, NLC_CLIP_CLAMP = 1, NLC_CLIP_DYNAMIC = 2 };
 enum { NLC_VAR_NONE = 0, NLC_VAR_FIXEDSMALL = 1, NLC_VAR_FIXEDLARGE = 2, NLC_VAR_LEARNED = 3 };
 /* kernel-selection policy of one nlc_conv2d call (nlc_conv_desc.policy).  AUTO is the production dispatch: the
- * LDS-halo kernel for stride-1 3x3 "same" convolutions with >= 256 (16x16 pixel x 128 channel) tiles, else the LDS-DMA
+ * LDS-halo kernel for stride-1 3x3 "same" convolutions with >= 128 (16x16 pixel x 128 channel) tiles, else the LDS-DMA
  * implicit-GEMM kernel (3x3 / 1x1), else the generic gather kernel.  The others exist so that parity tests and A/B
  * timings can pin a kernel per call; there is no process-wide switch. */
 enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3, NLC_CONV_FORCE_WIDE = 4 };

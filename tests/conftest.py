@@ -24,7 +24,7 @@ def pytest_collection_modifyitems(config, items):
 
 # The convolution kernel is chosen per call (nlc_conv_desc.policy).  Every GPU parity module that runs convolutions is
 # collected TWICE: under the production dispatch ("auto": what bench.py measures - the LDS-halo kernel only for launches
-# with >= 256 tiles, otherwise conv_fast / split-K / the generic kernel) and with the LDS-halo kernel forced for every
+# with >= 128 tiles, otherwise conv_fast / split-K / the generic kernel) and with the LDS-halo kernel forced for every
 # eligible shape (the small parity shapes would otherwise never reach it).
 @pytest.fixture(params=["auto", "halo"], ids=["production-dispatch", "forced-halo"])
 def conv_policy(request):

@@ -30,6 +30,10 @@ SHAPES = [  # (H, Cin, Cout, k, note); a trailing "ups" in the note = fused near
     (16, 1024, 3072, 1, "qkv 1024->3072 @16^2"),
     (16, 1024, 1024, 1, "proj 1024->1024 @16^2"),
     (256, 256, 6, 3, "out 256->6 @256^2"),
+    (16, 512, 1024, 3, "512->1024 @16^2"),
+    (16, 2048, 1024, 3, "2048->1024 @16^2"),
+    (16, 1024, 512, 3, "1024->512 @16^2"),
+    (16, 256, 1024, 3, "256->1024 @16^2"),
 ]
 
 
@@ -39,8 +43,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", type=int, default=-1, help="run only SHAPES[i] (for rocprofv3 --pmc passes)")
+    ap.add_argument("--first", type=int, default=0, help="skip SHAPES[:first]")
     ap.add_argument("--tuning", default="0", help="comma list of nlc_conv_desc.tuning values to A/B, interleaved in this one process")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--policy", default="auto", choices=sorted(ops.CONV_POLICIES), help="nlc_conv_desc.policy for every launch")
     ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a ResBlock)")
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights: same instruction stream, least energy per MFMA "
                     "(what the clock does to the rate: MI355X_MICROARCH.md 'DVFS give-back')")
@@ -48,8 +54,11 @@ def main():
     global SHAPES
     if args.only >= 0:
         SHAPES = SHAPES[args.only:args.only + 1]
+    elif args.first:
+        SHAPES = SHAPES[args.first:]
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    ops.CONV_POLICY = args.policy
     for H, cin, cout, k, note in SHAPES:
         x = torch.randn(args.batch, H, H, cin, device=dev).to(dt)
         w = torch.randn(cout, cin, k, k) / math.sqrt(cin * k * k)
