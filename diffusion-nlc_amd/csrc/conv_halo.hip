@@ -732,6 +732,7 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
 }
 
 int nlc_conv_halo_prologue_ok(const KParams& p, int dtype) {
+    if (p.tuning & 16) return 0;                     // A/B runs: GroupNorm prologue in conv_tall only (tuning bit 4)
     return dtype == NLC_BF16 && halo_eligible(p, dtype, nullptr) ? 1 : 0;
 }
 

@@ -260,7 +260,9 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     if (d->policy == NLC_CONV_GENERIC) return 0;
     KParams p{};
     geometry_only(d, p);
-    int P = nlc_conv_wide_stats_partials(p, dtype);
+    int P = nlc_conv_tall_stats_partials(p, dtype);
+    if (P > 0) return P;
+    P = nlc_conv_wide_stats_partials(p, dtype);
     if (P > 0) return P;
     P = nlc_conv_halo_stats_partials(p, dtype);
     if (P > 0) return P;
@@ -272,7 +274,7 @@ extern "C" int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype) 
     if (d->policy == NLC_CONV_GENERIC) return 0;
     KParams p{};
     geometry_only(d, p);
-    return nlc_conv_halo_prologue_ok(p, dtype);
+    return nlc_conv_tall_prologue_ok(p, dtype) || nlc_conv_halo_prologue_ok(p, dtype);
 }
 
 extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
@@ -321,7 +323,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  policy NLC_CONV_GENERIC forces the latter (A/B runs).
-    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_WIDE, "nlc_conv2d: bad policy %d", d->policy);
+    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_TALL, "nlc_conv2d: bad policy %d", d->policy);
     p.policy = d->policy; p.tuning = d->tuning;
     const bool force_generic = d->policy == NLC_CONV_GENERIC;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
@@ -329,7 +331,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     if (!force_generic) {
         int Pfast = 0;
         if (d->stats_out) {
-            const int Pwide = nlc_conv_wide_stats_partials(p, dtype);
+            const int Ptall = nlc_conv_tall_stats_partials(p, dtype);
+            const int Pwide = Ptall > 0 ? Ptall : nlc_conv_wide_stats_partials(p, dtype);
             const int Phalo = Pwide > 0 ? Pwide : nlc_conv_halo_stats_partials(p, dtype);
             Pfast = Phalo > 0 ? 0 : nlc_conv_fast_stats_partials(p, dtype);
             const int P = Phalo > 0 ? Phalo : Pfast;
@@ -337,9 +340,11 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / 8) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
             p.stats = (float*)d->stats_out; p.stats_P = P;
         }
-        NLC_REQUIRE(!p.gn_coef || nlc_conv_halo_prologue_ok(p, dtype),
+        NLC_REQUIRE(!p.gn_coef || nlc_conv_tall_prologue_ok(p, dtype) || nlc_conv_halo_prologue_ok(p, dtype),
                     "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue (ask nlc_conv2d_prologue_supported first)");
-        int rc = nlc_conv_wide_dispatch(p, dtype, (hipStream_t)stream);
+        int rc = nlc_conv_tall_dispatch(p, dtype, (hipStream_t)stream);
+        if (rc != NLC_EUNSUPPORTED) return rc;
+        rc = nlc_conv_wide_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;

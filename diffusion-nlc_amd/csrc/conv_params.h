@@ -42,6 +42,9 @@ int nlc_conv_halo_stats_partials(const KParams& p, int dtype);
 // conv_wide.hip: the 512-pixel-tile variant of the halo kernel (bf16, big launches); same conventions as the two below
 int nlc_conv_wide_stats_partials(const KParams& p, int dtype);
 int nlc_conv_wide_dispatch(const KParams& p, int dtype, hipStream_t stream);
+int nlc_conv_tall_stats_partials(const KParams& p, int dtype);     // conv_tall.hip: 256-pixel x 256-channel tiles
+int nlc_conv_tall_dispatch(const KParams& p, int dtype, hipStream_t stream);
+int nlc_conv_tall_prologue_ok(const KParams& p, int dtype);
 // conv_halo.hip: 1 if the halo kernel would take this launch AND can apply a GroupNorm prologue (bf16)
 int nlc_conv_halo_prologue_ok(const KParams& p, int dtype);
 // conv_halo.hip: 3x3 with the input halo resident in LDS; same return convention

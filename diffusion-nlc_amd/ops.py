@@ -129,7 +129,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
 CONV_PROFILE = None
 # Kernel-selection policy handed to every nlc_conv2d call (nlc_conv_desc.policy): "auto" is the production dispatch;
 # tests and A/B tools pin a kernel with "halo" (LDS-halo kernel for every eligible shape), "no_halo" or "generic".
-CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3, "wide": 4}
+CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3, "wide": 4, "tall": 5}
 CONV_POLICY = "auto"
 CONV_TUNING = 0              # nlc_conv_desc.tuning: schedule A/B switches for tools/ (0 in production)
 

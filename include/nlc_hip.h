@@ -49,10 +49,11 @@ enum { NLC_VAR_NONE = 0, NLC_VAR_FIXEDSMALL = 1, NLC_VAR_FIXEDLARGE = 2, NLC_VAR
  * LDS-halo kernel for stride-1 3x3 "same" convolutions with >= 128 (16x16 pixel x 128 channel) tiles, else the LDS-DMA
  * implicit-GEMM kernel (3x3 / 1x1), else the generic gather kernel.  The others exist so that parity tests and A/B
  * timings can pin a kernel per call; there is no process-wide switch. */
-enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3, NLC_CONV_FORCE_WIDE = 4 };
+enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3, NLC_CONV_FORCE_WIDE = 4,
+       NLC_CONV_FORCE_TALL = 5 };
 /* (FORCE_WIDE: the 512-pixel x 128-channel variant of the halo kernel, csrc/conv_wide.hip - opt-in only: it measured level
  *  with the 256-pixel kernel on 256^2 maps and slower below, so AUTO never selects it; shapes it does not support fall through
- *  to the AUTO order) */
+ *  to the AUTO order.  FORCE_TALL: the 256-pixel x 256-channel variant, csrc/conv_tall.hip) */
 
 int nlc_version(void);
 const char* nlc_last_error(void);

@@ -588,6 +588,117 @@ def test_groupnorm_coef_then_conv_equals_groupnorm_then_conv():
     assert getattr(fused, "_nlc_stats", None) is not None and err <= 1e-2 * scale, (err, scale)
 
 
+GNTALL_CASES = [
+    dict(B=2, Cin=128, H=32, W=48, Cout=256, split=64, silu=True, res=True),          # concat input (a group of four k-blocks spans both), edge + interior patches
+    dict(B=1, Cin=384, H=16, W=16, Cout=256, silu=False),                               # one patch per image; three coefficient groups
+    dict(B=2, Cin=128, H=16, W=32, Cout=512, silu=True, ups=True),                      # fused nearest-2x upsample of the normalised input, 2 N-tiles
+    dict(B=1, Cin=128, H=256, W=256, Cout=256, silu=True, emb=True),                    # 256 tiles; cross-tile streams over image-constant coefficients
+    dict(B=3, Cin=256, H=64, W=64, Cout=256, silu=True),                                # 48 tiles per image: the coefficient stage flips at image boundaries
+]
+
+
+@pytest.mark.parametrize("case", GNTALL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_tall_kernel_with_groupnorm_prologue(case):
+    """conv_tall_kernel<.., GN>: conv(act(a[b][c] x + b[b][c])) with the affine map (+SiLU) applied to the halo rows in LDS, once per
+    patch for all 256 output channels - against F.conv2d of the explicitly normalised input (zero padding AFTER the normalisation)."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(79)
+    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    a_ = torch.rand(B, Cin, generator=g) + 0.5
+    b_ = torch.randn(B, Cin, generator=g) * 0.3
+    xr = _rt(x, torch.bfloat16)
+    y = xr * a_[:, :, None, None] + b_[:, :, None, None]
+    if case.get("silu"):
+        y = F.silu(y)
+    y = _rt(y, torch.bfloat16)                                       # the prologue stores bf16 back into LDS
+    if case.get("ups"):
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+    ref = F.conv2d(y, _rt(w, torch.bfloat16), b, padding=1)
+    emb = res = None
+    if case.get("emb"):
+        emb = torch.randn(B, Cout, generator=g)
+        ref = ref + emb[:, :, None, None]
+    if case.get("res"):
+        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + _rt(res, torch.bfloat16)
+    coef = torch.zeros(B * Cin * 2 + 128)
+    coef[:B * Cin * 2] = torch.stack([a_, b_], dim=-1).reshape(-1)
+    coef = coef.to(_dev())
+    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    split = case.get("split")
+    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
+    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "tall"
+    try:
+        kw = dict(x1=x1, upsample2x=bool(case.get("ups")))
+        assert ops.conv2d(x0, pw, query_prologue=True, **kw)
+        got = ops.conv2d(x0, pw, gn_coef=coef, gn_act=1 if case.get("silu") else 0, emb=None if emb is None else emb.to(_dev()),
+                         res=None if res is None else _nhwc(res, torch.bfloat16), **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_POLICY = old
+    st = getattr(got, "_nlc_stats", None)
+    assert st is not None and st.shape[1] == (ref.shape[2] // 16) * (ref.shape[3] // 16) * 4, "the tall kernel did not take this launch"
+    _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (tall kernel, GroupNorm prologue)")
+
+
+TALL_CASES = [
+    dict(B=2, Cin=128, H=16, W=16, Cout=256, split=64, emb=True, res=True, scale=math.sqrt(0.5)),       # one patch per image, concat input
+    dict(B=1, Cin=64, H=32, W=48, Cout=512, bias=False),                                                  # interior + border patches, 2 N-tiles
+    dict(B=2, Cin=64, H=8, W=16, Cout=256, ups=True, res=True),                                           # fused nearest-2x upsample
+    dict(B=3, Cin=192, H=16, W=32, Cout=256, emb=True),                                                   # 6 k-blocks (three loop trips)
+    dict(B=2, Cin=128, H=256, W=256, Cout=256, res=True),                                                 # 512 tiles: two per persistent workgroup
+]
+
+
+@pytest.mark.parametrize("case", TALL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_tall_kernel(case):
+    """conv_tall_kernel (256-pixel x 256-channel tiles, 32-channel k-blocks, ring of four weight fragments) forced for shapes of
+    every kind it takes, against F.conv2d; plus its ride-along statistics."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(37)
+    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1 if case.get("bias", True) else None
+    xr = _rt(x, torch.bfloat16)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if case.get("ups") else xr
+    ref = F.conv2d(xin, _rt(w, torch.bfloat16), b, padding=1)
+    emb = res = None
+    if case.get("emb"):
+        emb = torch.randn(B, Cout + 8, generator=g)
+        ref = ref + emb[:, :Cout, None, None]
+    if case.get("res"):
+        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + _rt(res, torch.bfloat16)
+    ref = ref * case.get("scale", 1.0)
+    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    split = case.get("split")
+    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
+    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "tall"
+    try:
+        got = ops.conv2d(x0, pw, x1=x1, upsample2x=bool(case.get("ups")), emb=None if emb is None else emb.to(_dev())[:, :],
+                         res=None if res is None else _nhwc(res, torch.bfloat16), out_scale=case.get("scale", 1.0))
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_POLICY = old
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    st = getattr(got, "_nlc_stats", None)
+    assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 16) * 4, Cout // 8, 2), "the tall kernel did not take this launch"
+    _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (tall kernel)")
+    ch = got.float().cpu().view(B, Ho * Wo, Cout // 8, 8).double()
+    tot = st.double().sum(dim=1).cpu()
+    s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
+    assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
+    assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3
+
+
 WIDE_CASES = [
     dict(B=2, Cin=128, H=16, W=32, Cout=128, split=64, emb=True, res=True, scale=math.sqrt(0.5)),       # one patch per image, concat input
     dict(B=1, Cin=64, H=32, W=64, Cout=256, bias=False),                                                  # interior + border patches, 2 N-tiles
