@@ -152,8 +152,13 @@ __device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v
 
 __global__ __launch_bounds__(RT) void quantile_kernel(const float* __restrict__ x, float q, float max_value,
                                                      float* __restrict__ s_out, int64_t D) {
-    __shared__ unsigned hist[256];
+    // one histogram per wave: the digits of a pass cluster in a handful of bins (pass 0 sees the exponents of one image), and
+    // 1024 threads hammering the same LDS words serialised the whole pass (257 us per launch with a single histogram)
+    constexpr int NW = RT / 64;
+    __shared__ unsigned histw[NW][256];
+    unsigned* hist = histw[0];
     __shared__ unsigned s_prefix, s_k, s_cnt_le, s_next;
+    const int wv = threadIdx.x >> 6;
     const float* row = x + (int64_t)blockIdx.x * D;
     // rank arithmetic in f32 exactly as ATen does: rank = q * (n-1)
     const float rank = q * (float)(D - 1);
@@ -163,11 +168,28 @@ __global__ __launch_bounds__(RT) void quantile_kernel(const float* __restrict__ 
     unsigned prefix = 0, mask = 0;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        for (int i = threadIdx.x; i < 256; i += RT) hist[i] = 0;
+        for (int i = threadIdx.x; i < NW * 256; i += RT) (&histw[0][0])[i] = 0;
         __syncthreads();
-        for (int64_t i = threadIdx.x; i < D; i += RT) {
+        // eight loads in flight per thread (one per iteration made every pass a chain of 192 dependent L2 round trips)
+        int64_t i = threadIdx.x;
+        for (; i + 7 * RT < D; i += 8 * RT) {
+            unsigned u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = abs_bits(row[i + e * RT]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if ((u[e] & mask) == prefix) atomicAdd(&histw[wv][(u[e] >> shift) & 255u], 1u);
+        }
+        for (; i < D; i += RT) {
             const unsigned u = abs_bits(row[i]);
-            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            if ((u & mask) == prefix) atomicAdd(&histw[wv][(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {                     // fold the per-wave histograms (integer counts: order-free)
+            unsigned a = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) a += histw[w][threadIdx.x];
+            hist[threadIdx.x] = a;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -187,9 +209,19 @@ __global__ __launch_bounds__(RT) void quantile_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) { s_cnt_le = 0; s_next = 0x7fffffffu; }
     __syncthreads();
     unsigned cnt = 0, nxt = 0x7fffffffu;
-    for (int64_t i = threadIdx.x; i < D; i += RT) {
-        const unsigned u = abs_bits(row[i]);
-        if (u <= prefix) ++cnt; else nxt = min(nxt, u);
+    {
+        int64_t i = threadIdx.x;
+        for (; i + 7 * RT < D; i += 8 * RT) {
+            unsigned u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = abs_bits(row[i + e * RT]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { if (u[e] <= prefix) ++cnt; else nxt = min(nxt, u[e]); }
+        }
+        for (; i < D; i += RT) {
+            const unsigned u = abs_bits(row[i]);
+            if (u <= prefix) ++cnt; else nxt = min(nxt, u);
+        }
     }
     atomicAdd(&s_cnt_le, cnt);
     atomicMin(&s_next, nxt);
