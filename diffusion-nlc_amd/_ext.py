@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NLC_HIP_LIB", _HERE / "libnlc_hip.so"))     # override: kernel A/B experiments only
 BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
 
-ABI_VERSION = 2                 # NLC_ABI_VERSION of include/nlc_hip.h
+ABI_VERSION = 3                 # NLC_ABI_VERSION of include/nlc_hip.h
 NLC_F32, NLC_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
@@ -58,6 +58,7 @@ class ConvDesc(C.Structure):
         ("gn_coef", C.c_void_p),
         ("gn_act", C.c_int32),
         ("tuning", C.c_int32),
+        ("res_upsample2x", C.c_int32),
     ]
 
 

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg] + cbias[j * 4 + reg];
                 if (has_res) {
-                    const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
+                    const T* rp = reinterpret_cast<const T*>(p.res) + res_row_m(p, m) * p.Cout + n;
                     const uint4 r0 = *reinterpret_cast<const uint4*>(rp), r1 = *reinterpret_cast<const uint4*>(rp + 8);
                     float rr[16];
                     chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
             for (int k = 0; k < 16; ++k) v[k] += (n + k < p.Cout) ? ev[k] : 0.f;
         }
         if (p.res) {
-            const T* rp = reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n;
+            const T* rp = reinterpret_cast<const T*>(p.res) + res_row_m(p, m) * p.Cout + n;
             if (full) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     float r[4] = {v.x, v.y, v.z, v.w};
+    const int64_t roff = res_row_m(p, m) * p.Cout + n;
     const int HWo = p.Hout * p.Wout;
     const int b = (int)(m / HWo);
 #pragma unroll
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
         float x = r[k];
         if (p.bias) x += p.bias[n + k];
         if (p.emb) x += p.emb[(int64_t)b * p.emb_stride + n + k];
-        if (p.res) x += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + off + k);
+        if (p.res) x += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + roff + k);
         r[k] = apply_act(x * p.out_scale, p.act);
     }
     if (p.out_mode == NLC_OUT_NHWC) {

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg];
                     if (has_res) {
-                        const T* rp = reinterpret_cast<const T*>(p.res) + m * p.Cout + n;
+                        const T* rp = reinterpret_cast<const T*>(p.res) + res_row(p, t.tb, t.y0 + wm * 4 + i, t.x0 + fr) * p.Cout + n;
                         const uint4 r0 = *reinterpret_cast<const uint4*>(rp), r1 = *reinterpret_cast<const uint4*>(rp + 8);
                         float rr[16];
                         chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
@@ -447,16 +447,17 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     for (int k = 0; k < 16; ++k) { v[k] += cbias_[k]; v[k] += cemb_[k]; }     // reference order: + bias, then + emb
                 }
                 if (p.res) {
+                    const int64_t mres = res_row(p, t.tb, t.y0 + wm * 4 + i, t.x0 + fr);
                     if (full) {
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
                             float rr[PER];
-                            chunk_to_f32<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + m * p.Cout + n + c * PER), rr);
+                            chunk_to_f32<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + mres * p.Cout + n + c * PER), rr);
 #pragma unroll
                             for (int k = 0; k < PER; ++k) v[c * PER + k] += rr[k];
                         }
                     } else {
-                        const T* rp = reinterpret_cast<const T*>(p.res) + m * p.Cout + n;
+                        const T* rp = reinterpret_cast<const T*>(p.res) + mres * p.Cout + n;
 #pragma unroll
                         for (int k = 0; k < 16; ++k) if (n + k < p.Cout) v[k] += ElemTraits<T>::load(rp + k);
                     }

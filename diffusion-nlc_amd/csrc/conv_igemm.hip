@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p
                 float v = acc[i][j][reg];
                 if (p.bias) v += p.bias[n];
                 if (p.emb) v += p.emb[(int64_t)b * p.emb_stride + n];
-                if (p.res) v += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n);
+                if (p.res) v += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + res_row_m(p, m) * p.Cout + n);
                 v *= p.out_scale;
                 v = apply_act(v, p.act);
                 if (p.out_mode == NLC_OUT_NHWC)
@@ -314,7 +314,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     p.ups = d->upsample2x ? 1 : 0;
     p.w = (const char*)d->w; p.Cin_pad = d->Cin_pad; p.Cout_pad = d->Cout_pad;
     p.bias = d->bias; p.emb = d->emb; p.emb_stride = d->emb_stride;
-    p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act;
+    p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act; p.res_ups = d->res_upsample2x ? 1 : 0;
+    NLC_REQUIRE(!d->res_upsample2x || (d->res && d->Hout % 2 == 0 && d->Wout % 2 == 0), "nlc_conv2d: res_upsample2x needs a residual and even Hout, Wout");
     p.out = (char*)d->out; p.out_mode = d->out_mode;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
     p.ksplit = 1; p.partial = nullptr;

@@ -28,7 +28,20 @@ struct KParams {
     int policy;         // NLC_CONV_* kernel-selection policy of this call (nlc_conv_desc.policy)
     int tuning;         // A/B switches (nlc_conv_desc.tuning)
     const float* gn_coef; int gn_act;   // conv_halo (bf16) only: input = act(a x + b) applied in LDS (nlc_conv_desc.gn_coef)
+    int res_ups;        // res is [B][Hout/2][Wout/2][Cout]: output pixel (y, x) adds res pixel (y >> 1, x >> 1) (nlc_conv_desc.res_upsample2x)
 };
+
+// row (pixel index) of the residual tensor that output pixel (y, x) of image tb / output row m adds
+__device__ __forceinline__ int64_t res_row(const KParams& p, int tb, int y, int x) {
+    return p.res_ups ? ((int64_t)tb * (p.Hout >> 1) + (y >> 1)) * (p.Wout >> 1) + (x >> 1) : ((int64_t)tb * p.Hout + y) * p.Wout + x;
+}
+__device__ __forceinline__ int64_t res_row_m(const KParams& p, int64_t m) {
+    if (!p.res_ups) return m;
+    const int HWo = p.Hout * p.Wout;
+    const int b = (int)(m / HWo), rem = (int)(m - (int64_t)b * HWo);
+    const int y = rem / p.Wout, x = rem - y * p.Wout;
+    return ((int64_t)b * (p.Hout >> 1) + (y >> 1)) * (p.Wout >> 1) + (x >> 1);
+}
 
 // conv_fast.hip: NLC_OK, NLC_ELAUNCH, or NLC_EUNSUPPORTED (shape not handled -> use the generic kernel)
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WT, 2) void conv_tall_kernel(const KParams p) {
             for (int tt = 0; tt < 4; ++tt) {
                 const int64_t m = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4 + tt) * p.Wout + t.x0 + fr;
                 T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
-                const T* rp = reinterpret_cast<const T*>(p.res) + m * p.Cout + n;
+                const T* rp = reinterpret_cast<const T*>(p.res) + res_row(p, t.tb, t.y0 + wm * 4 + tt, t.x0 + fr) * p.Cout + n;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {                                 // 8 channels = N-tiles 4 g + 2 c, 4 g + 2 c + 1
                     float v[8];

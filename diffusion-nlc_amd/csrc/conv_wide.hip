@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WT, 2) void conv_wide_kernel(const KParams p) {
         for (int tt = 0; tt < 8; ++tt) {
             const int64_t m = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4 + (tt >> 1)) * p.Wout + t.x0 + 16 * (tt & 1) + fr;
             T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
-            const T* rp = reinterpret_cast<const T*>(p.res) + m * p.Cout + n;
+            const T* rp = reinterpret_cast<const T*>(p.res) + res_row(p, t.tb, t.y0 + wm * 4 + (tt >> 1), t.x0 + 16 * (tt & 1) + fr) * p.Cout + n;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {                                     // 8 channels = N-tiles 2c, 2c+1
                 float v[8];

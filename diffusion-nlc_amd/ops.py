@@ -139,7 +139,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
            emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
            act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True,
            emit_stats: bool = True, allow_split: bool = False, gn_coef: Optional[torch.Tensor] = None,
-           gn_act: int = ACT_NONE, query_prologue: bool = False):
+           gn_act: int = ACT_NONE, query_prologue: bool = False, res_upsample2x: bool = False):
     """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1).
     ``emit_stats``: let the epilogue also write the GroupNorm statistics of the output when the launch supports it
     (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass.
@@ -147,7 +147,9 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
     summation order never depends on the shape.
     ``gn_coef`` / ``gn_act``: the GroupNorm (+FiLM) (+SiLU) in front of this convolution, applied by the convolution itself
     on its way through LDS (coefficients from ``groupnorm_coef``); ``query_prologue=True`` only asks whether this launch
-    could do that (returns bool, launches nothing)."""
+    could do that (returns bool, launches nothing).
+    ``res_upsample2x``: ``res`` is [B, Hout/2, Wout/2, Cout] and is added nearest-2x upsampled (the skip branch of an
+    up-sampling ResBlock, src/unet_adm.py:186-190) - read in place, no upsampled copy in HBM."""
     lib = _ext.load()
     dt = pw.dtype
     linear = x0.dim() == 2
@@ -177,8 +179,12 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         out = torch.empty(B, Hout, Wout, pw.Cout, device=x0.device, dtype=dt)
     if res is not None:
         _need(res, dt, "conv2d res")
-        if res.numel() != B * Hout * Wout * pw.Cout:
+        if res_upsample2x and (Hout % 2 or Wout % 2):
+            raise ValueError("conv2d: res_upsample2x needs even output dims")
+        if res.numel() != B * Hout * Wout * pw.Cout // (4 if res_upsample2x else 1):
             raise ValueError("conv2d: residual shape mismatch")
+    elif res_upsample2x:
+        raise ValueError("conv2d: res_upsample2x without a residual")
     emb_stride = 0
     if emb is not None:
         # usually a row-strided view into the network's stacked embedding projections (EmbBank)
@@ -192,7 +198,8 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  upsample2x=1 if upsample2x else 0, w=pw.w.data_ptr(), Cin_pad=pw.Cin_pad, Cout_pad=pw.Cout_pad,
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
-                 out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY], tuning=CONV_TUNING)
+                 out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY], tuning=CONV_TUNING,
+                 res_upsample2x=1 if res_upsample2x else 0)
     if query_prologue:
         return bool(lib.nlc_conv2d_prologue_supported(C.byref(d), dtype_enum(dt)))
     if gn_coef is not None:

@@ -73,15 +73,19 @@ class _ResBlock:
             h = ops.conv2d(h, self.c1, emb=c1_emb)
         else:                                                  # GroupNorm+SiLU applied inside the conv's LDS prologue when it can be
             h = self.n1.then_conv(x, self.c1, silu=True, x1=x1, upsample2x=self.up, emb=c1_emb)
-        if self.up:
+        res_ups = False
+        if self.up and self.skip is None:
+            res_ups = True                                     # x_upd(x): read nearest-2x upsampled by the conv's epilogue, never materialised
+        elif self.up:
             x = ops.upsample2x(x)
         if self.skip is not None:
             res = ops.conv2d(x, self.skip, x1=x1)
         else:
             res = x
         if self.scale_shift and emb is not None:
-            return self.n2.then_conv(h, self.c2, silu=True, scale=emb[:, :self.cout], shift=emb[:, self.cout:2 * self.cout], res=res)
-        return self.n2.then_conv(h, self.c2, silu=True, res=res)
+            return self.n2.then_conv(h, self.c2, silu=True, scale=emb[:, :self.cout], shift=emb[:, self.cout:2 * self.cout], res=res,
+                                     res_upsample2x=res_ups)
+        return self.n2.then_conv(h, self.c2, silu=True, res=res, res_upsample2x=res_ups)
 
 
 class _Attention:

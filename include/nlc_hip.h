@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 2
+#define NLC_ABI_VERSION 3
 
 enum { NLC_F32 = 0, NLC_BF16 = 1 };
 enum { NLC_OK = 0, NLC_EINVAL = -1, NLC_ELAUNCH = -2, NLC_EUNSUPPORTED = -3 };
@@ -128,6 +128,9 @@ typedef struct nlc_conv_desc {
                          /* nlc_conv2d_prologue_supported(desc, dtype) returns 1 take it (bf16, LDS-halo kernel).                     */
     int32_t tuning;      /* 0 in production.  Bit mask of kernel A/B switches for in-process timing experiments (tools/): */
                          /* results are identical for every value, only the schedule changes (see conv_halo.hip).          */
+    int32_t res_upsample2x; /* 1: res is [B][Hout/2][Wout/2][Cout] and output pixel (y, x) adds res pixel (y/2, x/2) - the        */
+                         /* skip branch x_upd(x) of an up-sampling ResBlock (src/unet_adm.py:186-190, nearest-2x Upsample) read    */
+                         /* in place of a materialised upsampled copy.  Hout, Wout must be even.                                  */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);

@@ -588,6 +588,43 @@ def test_groupnorm_coef_then_conv_equals_groupnorm_then_conv():
     assert getattr(fused, "_nlc_stats", None) is not None and err <= 1e-2 * scale, (err, scale)
 
 
+RESUPS_CASES = [
+    # (B, Cin, H, W, Cout, policy, dtype): every kernel family that reads a residual
+    (2, 64, 32, 32, 128, "halo", torch.bfloat16),        # halo kernel, hot epilogue
+    (1, 64, 16, 48, 72, "halo", torch.bfloat16),         # halo kernel, general epilogue (ragged Cout)
+    (2, 64, 16, 16, 128, "no_halo", torch.bfloat16),     # conv_fast<9>, hot epilogue
+    (16, 128, 8, 8, 128, "auto", torch.bfloat16),        # conv_fast<9> + split-K reduce
+    (2, 40, 12, 20, 24, "generic", torch.bfloat16),      # generic implicit GEMM
+    (2, 64, 32, 64, 128, "wide", torch.bfloat16),
+    (2, 64, 32, 32, 256, "tall", torch.bfloat16),
+    (2, 32, 16, 16, 64, "auto", torch.float32),          # f32 parity path
+]
+
+
+@pytest.mark.parametrize("case", RESUPS_CASES, ids=lambda c: f"B{c[0]}-Cin{c[1]}-{c[2]}x{c[3]}-Cout{c[4]}-{c[5]}-{'bf16' if c[6] == torch.bfloat16 else 'f32'}")
+def test_conv2d_residual_read_nearest_2x_upsampled(case):
+    """nlc_conv_desc.res_upsample2x: out = conv(x) + upsample2x(res_small) - the skip branch of an up-sampling ResBlock
+    (src/unet_adm.py:186-190) read in place by every epilogue that takes a residual."""
+    from diffusion_nlc_amd import ops
+    B, Cin, H, W, Cout, policy, dtype = case
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    rs = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(_rt(x, dtype), _rt(w, dtype), b, padding=1) + F.interpolate(_rt(rs, dtype), scale_factor=2, mode="nearest")
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = policy
+    try:
+        got = ops.conv2d(_nhwc(x, dtype), ops.pack_conv(w, b, dtype, _dev()), res=_nhwc(rs, dtype), res_upsample2x=True)
+        same = ops.conv2d(_nhwc(x, dtype), ops.pack_conv(w, b, dtype, _dev()), res=ops.upsample2x(_nhwc(rs, dtype)))
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_POLICY = old
+    _close(got.permute(0, 3, 1, 2), ref, _tol(dtype), f"conv2d res_upsample2x ({policy})")
+    assert torch.equal(got, same)                 # identical arithmetic to the materialised upsample
+
+
 GNTALL_CASES = [
     dict(B=2, Cin=128, H=32, W=48, Cout=256, split=64, silu=True, res=True),          # concat input (a group of four k-blocks spans both), edge + interior patches
     dict(B=1, Cin=384, H=16, W=16, Cout=256, silu=False),                               # one patch per image; three coefficient groups
