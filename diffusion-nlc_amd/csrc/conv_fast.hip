@@ -73,9 +73,9 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 
 template <int N> __device__ __forceinline__ void dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// STAGES = 2: two workgroups per CU hide each other's DMA latency (the many-tile launches).  STAGES = 3 / 4: one workgroup per
-// CU with the DMA of 2 / 3 k-steps in flight behind a counted wait - for the launches with at most one workgroup per CU
-// (attention projections, the 8x8 / 16x16 levels), where a k-step otherwise costs a full memory round trip.
+// STAGES = 2 (the only instantiation shipped): two workgroups per CU hide each other's DMA latency.  STAGES = 3 / 4 - one workgroup
+// per CU with the DMA of 2 / 3 k-steps in flight behind a counted wait - were measured on every shape of tools/conv_bench.py and
+// are slower everywhere, by 10-45 % (profiles/r02_summary.md): eight resident waves matter more than the deeper pipeline.
 template <typename T, int TAPS, int STAGES>
 __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -504,14 +504,6 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     return s < 2 ? 1 : s;
 }
 
-// Pipeline depth (bf16): tuning bits 1-2 pin it for A/B runs (2 -> 3 stages, 4 -> 4 stages, 6 -> 2 stages)
-int nlc_conv_fast_stages(const KParams& p) {
-    const int pin = p.tuning & 6;
-    if (pin == 2) return 3;
-    if (pin == 4) return 4;
-    return 2;
-}
-
 // GroupNorm statistics ride along on the fast path when the N-tiles are whole and the output is bf16 NHWC: from the conv
 // epilogue if every 128-pixel tile lies inside one image, from the split-K reduce kernel when K is split
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
@@ -522,15 +514,20 @@ int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
     return (HWo / BM) * 2;
 }
 
+// the reduce + epilogue pass over [ksplit][M][Cout] f32 partial sums (p.partial, p.ksplit), also for the halo kernel's split-K launches
+int nlc_conv_splitk_reduce(const KParams& p, int dtype, hipStream_t stream) {
+    const int64_t quads = (int64_t)p.M * (p.Cout >> 2);
+    if (dtype == NLC_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16_raw>), dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { nlc_set_error("nlc_conv2d(split-K reduce): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
+    return NLC_OK;
+}
+
 // returns NLC_EUNSUPPORTED when the shape is not one the fast path handles (caller falls back)
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!fast_shape(p)) return NLC_EUNSUPPORTED;
     const bool k3 = p.KH == 3;
-    if (dtype == NLC_BF16) {
-        const int st = nlc_conv_fast_stages(p);
-        if (st == 4) return k3 ? launch_fast<bf16_raw, 9, 4>(p, stream) : launch_fast<bf16_raw, 1, 4>(p, stream);
-        if (st == 3) return k3 ? launch_fast<bf16_raw, 9, 3>(p, stream) : launch_fast<bf16_raw, 1, 3>(p, stream);
-        return k3 ? launch_fast<bf16_raw, 9, 2>(p, stream) : launch_fast<bf16_raw, 1, 2>(p, stream);
-    }
+    if (dtype == NLC_BF16) return k3 ? launch_fast<bf16_raw, 9, 2>(p, stream) : launch_fast<bf16_raw, 1, 2>(p, stream);
     return k3 ? launch_fast<float, 9, 2>(p, stream) : launch_fast<float, 1, 2>(p, stream);
 }

@@ -87,7 +87,7 @@ __device__ __forceinline__ void glds16h_s(unsigned voff, const void* sbase, unsi
 }
 template <int N> __device__ __forceinline__ void dma_wait_h() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-struct TileH { int tb, y0, x0, n0; };
+struct TileH { int tb, y0, x0, n0, cb0, cb1, ks, tix; };     // cb0 / cb1 / ks / tix: channel-block range, split index, tile index (SPLIT only)
 
 // ---- diagnostic build only (-DHALO_STAMP): s_memtime stamps around the phases of ONE k-step (tile 1, cb 1, tap 4) of
 //      workgroup 0, per wave; read back with nlc_debug_halo_stamps.  No stamp executes in the normal build.
@@ -113,7 +113,12 @@ __device__ unsigned long long g_halo_tile[8][4];   // per wave: s_memtime before
 #define ESTAMP(i) do {} while (0)
 #endif
 
-template <typename T, bool GN>
+// SPLIT: split-K for launches with fewer tiles than CUs (the 16x16 level): a list entry is (tile, channel-block range); every
+// workgroup writes its accumulators as raw f32 partial sums [split][M][Cout], and the workgroup that ARRIVES LAST at a tile (one
+// atomic counter per tile, self-resetting) reads all of the tile's partials back in split order - a fixed summation order whoever
+// is last - adds bias / embedding and runs the normal epilogue.  No reduce pass, statistics in the usual four-per-patch form.
+// A separate instantiation: the plain kernel keeps its code.
+template <typename T, bool GN, bool SPLIT = false>
 __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = ElemTraits<T>::kPerChunk;
@@ -124,7 +129,8 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     //      chunk of the tile list (N-tile fastest, so neighbours in time share the halo and the weights in that
     //      XCD's L2); the workgroups of an XCD walk their chunk with stride (workgroups per XCD).
     const int tiles_x = p.Wout / PATCH, tiles_y = p.Hout / PATCH;          // (Hout, Wout) = 2 x (Hin, Win) with the fused nearest-2x upsample
-    const int nblk = p.B * tiles_y * tiles_x * p.NT;
+    const int ksp = SPLIT ? p.ksplit : 1;
+    const int nblk = p.B * tiles_y * tiles_x * p.NT * ksp;
     const int G = gridDim.x;
     const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
     const int gx = (G - xcd + 7) >> 3;
@@ -132,12 +138,19 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     const int chunk_start = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
     const int chunk_len = cq + (xcd < cr ? 1 : 0);
     auto decode = [&](int tl) {
-        const int id = chunk_start + tl;
+        int id = chunk_start + tl;
+        int ks = 0, cb0 = 0, cb1 = 0, tix = 0;
+        if constexpr (SPLIT) {
+            const int nc = p.Cin_pad / KBE;
+            const int q = id / ksp;
+            ks = id - q * ksp; id = q; tix = q;
+            cb0 = (nc * ks) / ksp; cb1 = (nc * (ks + 1)) / ksp;
+        }
         const int mt = id / p.NT, nt = id - mt * p.NT;
         const int tb = mt / (tiles_y * tiles_x);
         const int trem = mt - tb * tiles_y * tiles_x;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        return TileH{tb, ty * PATCH, tx * PATCH, nt * BN};
+        return TileH{tb, ty * PATCH, tx * PATCH, nt * BN, cb0, cb1, ks, tix};
     };
     int tl = wi;
     if (tl >= chunk_len) return;                     // workgroup-uniform
@@ -250,8 +263,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         const int gchunk = lslot ^ (row & 7);
         woff[j] = (unsigned)((int64_t)ch * wrow + (int64_t)gchunk * PER * ES);      // < 128 * 9 * Cin_pad * ES: fits 32 bits
     }
-    auto issue_B = [&](int n0, int kt, int bstage) {
-        const int cb = kt / 9, tap = kt - cb * 9;
+    auto issue_B = [&](int n0, int cbb, int kt, int bstage) {       // cbb: first channel block of the tile kt counts from (0 unless SPLIT)
+        const int cbl = kt / 9, tap = kt - cbl * 9;
+        const int cb = cbb + cbl;
         const unsigned base = ldsB + bstage * B_STAGE + wave * 8 * KB_BYTES;
         const char* sb = p.w + (int64_t)n0 * wrow + ((int64_t)tap * p.Cin_pad + cb * KBE) * ES;     // wave-uniform
 #pragma unroll
@@ -368,12 +382,78 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #endif
         ESTAMP(0);
         float cnext[16];
-        load_cadd(nx, cnext);                        // in flight while this tile is stored
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cnext[k] = 0.f;           // raw partial sums: bias / embedding are added by the last arriver
+        } else {
+            load_cadd(nx, cnext);                    // in flight while this tile is stored
+        }
         ESTAMP(1);
         const int n = t.n0 + wn * 64 + fq * 16;
         float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};        // this lane's two 8-channel chunks over its 4 pixels
         bool done = false;
+        bool parked = false;                         // SPLIT: this workgroup was not the last to arrive at its tile - no output from it
+        if constexpr (SPLIT) {                       // dispatch: bf16, Cout % 128 == 0
+            // The partial sums cross workgroups that may sit on different XCDs (one L2 each): they are written and read with relaxed
+            // AGENT-scope atomic accesses (write-through / cache-bypassing), ordered by the arrival counter.  No release fence: on
+            // this chip an agent-scope release writes back the XCD's whole dirty L2 (measured: +80 us per launch).
+            __shared__ int s_last;
+            // layout [split][tile][wave][accumulator register 0..63][lane]: a wave-instruction writes / reads 256 contiguous bytes (in the
+            // [M][Cout] layout every lane of a dword access touched a cache line of its own: +130 us per launch), and the last
+            // arriver's lane (wave, lane) finds exactly its own elements at its own offset.  Same size: 256 x 128 floats per tile.
+            const int ntile = nblk / ksp;
+            auto pbase = [&](int sp) { return p.partial + ((((int64_t)sp * ntile + t.tix) * 8 + wave) * 64) * 64 + lane; };
+            {
+                float* pp = pbase(t.ks);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            __hip_atomic_store(pp + (i * 16 + j * 4 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this lane's partial stores have been acknowledged ...
+            __syncthreads();                         // ... and every lane's, before the workgroup's arrival is counted
+            if (tid == 0) {
+                int* cnt = reinterpret_cast<int*>(p.partial + (int64_t)ksp * p.M * p.Cout) + t.tix;
+                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == ksp - 1;
+                if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-resetting
+                s_last = last;
+            }
+            __syncthreads();
+            const bool last = s_last != 0;           // workgroup-uniform
+            __syncthreads();                         // s_last may be rewritten by the next tile's epilogue
+            if (last) {
+                float cthis[16];
+                load_cadd(t, cthis);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // two splits' loads of a pixel row at a time (32 in flight), then the adds in the fixed order split 0, 1, ...
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cthis[j * 4], cthis[j * 4 + 1], cthis[j * 4 + 2], cthis[j * 4 + 3]};
+                    for (int s0 = 0; s0 < ksp; s0 += 2) {
+                        float tmp[2][16];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float* pp = pbase(s0 + u < ksp ? s0 + u : 0) + i * 16 * 64;
+#pragma unroll
+                            for (int k = 0; k < 16; ++k)
+                                tmp[u][k] = s0 + u < ksp ? __hip_atomic_load(pp + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + tmp[0][j * 4 + r]) + tmp[1][j * 4 + r];     // + 0.f past ksp: exact
+                    }
+                }
+            } else {
+                parked = true; done = true;
+            }
+        }
         if constexpr (FOLD) {
+            if (!done)
             // hot path (bf16, whole 16-channel slice, NHWC): the option switches are hoisted out of the element loops;
             // measured with stamps, the general path below spent ~9 k cycles per tile on ~19 VALU per output element
             if (vec_ok && n + 16 <= p.Cout && p.out_mode == NLC_OUT_NHWC) {
@@ -499,7 +579,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         }
         ESTAMP(2);
         if constexpr (sizeof(T) == 2) {
-            if (p.stats && n + 16 <= p.Cout) {
+            if (p.stats && n + 16 <= p.Cout && !parked) {
                 // reduce over the 16 pixel lanes (fr) of this quarter-wave in a fixed order, then one 16-byte store per
                 // (patch, M-wave, 16-channel slice): stats[b][partial][chunk][{sum, sumsq}]
                 const float r4[4] = {row16_sum(gsum[0]), row16_sum(gsq[0]), row16_sum(gsum[1]), row16_sum(gsq[1])};
@@ -518,15 +598,24 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // ---- prologue (first tile only): halo of block 0, weights of steps 0..2
     {
         float c0[16];
-        load_cadd(cur, c0);
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) c0[k] = 0.f;
+        } else {
+            load_cadd(cur, c0);
+        }
         init_acc(c0);
     }
-    halo_addr(cur, 0);
+    auto t_cb0 = [&](const TileH& t) { if constexpr (SPLIT) return t.cb0; else return 0; };
+    auto t_cb1 = [&](const TileH& t) { if constexpr (SPLIT) return t.cb1; else return ncb; };
+    auto t_seg = [&](const TileH& t) { return (SPLIT && p.C1 > 0 && t.cb0 >= cbs1) ? 1 : 0; };
+    auto t_nk = [&](const TileH& t) { if constexpr (SPLIT) return (t.cb1 - t.cb0) * 9; else return nk; };
+    halo_addr(cur, t_seg(cur));
     if (coef_wave) issue_coef(0, 0);
-    issue_A(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
-    issue_B(cur.n0, 0, 0);
-    issue_B(cur.n0, min(1, nk - 1), 1);
-    issue_B(cur.n0, min(2, nk - 1), 2);
+    issue_A(t_cb0(cur), 0, std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{});
+    issue_B(cur.n0, t_cb0(cur), 0, 0);
+    issue_B(cur.n0, t_cb0(cur), min(1, t_nk(cur) - 1), 1);
+    issue_B(cur.n0, t_cb0(cur), min(2, t_nk(cur) - 1), 2);
     dma_wait_h<NB>();                                // halo 0 + weights 0,1 landed (weights 2 may fly)
     __syncthreads();
     if (has_gn) {                                    // first halo of the launch: normalise all six own instructions at once
@@ -549,8 +638,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         const bool has_next = tl + gx < chunk_len;
         const TileH nxt = has_next ? decode(tl + gx) : cur;
         int kt = 0;
-        for (int cb = 0; cb < ncb; ++cb) {
-            const bool last_cb = cb + 1 == ncb;
+        const int c_end = t_cb1(cur), nkt = t_nk(cur);
+        for (int cb = t_cb0(cur); cb < c_end; ++cb) {
+            const bool last_cb = cb + 1 == c_end;
             const bool more = !last_cb || has_next;  // a halo follows this one in the stream
 #ifdef HALO_STAMP
             const bool stamp_on = blockIdx.x == 0 && tl == wi + gx && cb == 1;
@@ -570,17 +660,17 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // stale-but-valid LDS; neither result is used (straight-line body, no data-dependent branches).
                 auto issue_dma = [&]() {
                     const int k3 = kt + wdist;
-                    const bool wrap = k3 >= nk;
-                    issue_B(wrap ? nxt.n0 : cur.n0, wrap ? (has_next ? k3 - nk : nk - 1) : k3, (bcur + wdist) & 3);
+                    const bool wrap = k3 >= nkt;
+                    issue_B(wrap ? nxt.n0 : cur.n0, wrap && has_next ? t_cb0(nxt) : t_cb0(cur), wrap ? (has_next ? k3 - nkt : nkt - 1) : k3, (bcur + wdist) & 3);
                     // the next halo goes out two instructions per step over taps 0-2, AFTER the step's weights (needed first)
                     if constexpr (tap <= 2) {
                         if (more) {
                             if constexpr (tap == 0) {
-                                if (last_cb) halo_addr(nxt, 0);
+                                if (last_cb) halo_addr(nxt, t_seg(nxt));
                                 else if (p.C1 > 0 && cb + 1 == cbs1) halo_addr(cur, 1);
                                 if (coef_wave) issue_coef(last_cb ? 0 : cb + 1, hs ^ 1);     // BEFORE the halo rows: retired first
                             }
-                            issue_A(last_cb ? 0 : cb + 1, hs ^ 1, std::integral_constant<int, 2 * tap>{}, std::integral_constant<int, 2>{});
+                            issue_A(last_cb ? t_cb0(nxt) : cb + 1, hs ^ 1, std::integral_constant<int, 2 * tap>{}, std::integral_constant<int, 2>{});
                         }
                     }
                 };
@@ -685,16 +775,16 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     dma_wait_h<0>();          // the redundant tail fetches
 }
 
-template <typename T, bool GN>
+template <typename T, bool GN, bool SPLIT = false>
 int launch_halo(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
     const int slot = nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, GN, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
     });
     const int ncu = once.ncu[slot];
-    const int nblk = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT;
+    const int nblk = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT * (SPLIT ? p.ksplit : 1);
     const int grid = nblk < ncu ? nblk : ncu;        // one persistent workgroup per CU (154 KiB of LDS each)
-    hipLaunchKernelGGL((conv_halo_kernel<T, GN>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
+    hipLaunchKernelGGL((conv_halo_kernel<T, GN, SPLIT>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(halo): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
@@ -726,28 +816,61 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     const int kbe = dtype == NLC_BF16 ? MmaH<bf16_raw>::KBE : MmaH<float>::KBE;
     if (p.C0 % kbe || p.C1 % kbe || p.Cin_pad / kbe > 128) return false;
     if ((int64_t)p.B * p.Hout * p.Wout >= (1ll << 31)) return false;
-    const int blocks = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT;
-    // >= 128 tiles: at 128-255 (the 16x16 level of ADM-256 at B = 16) half the CUs idle, and the kernel still beats conv_fast +
-    // split-K + reduce (1024->1024: 100 vs 114 us, 512->1024: 55 vs 70, 256->1024: 34 vs 52; 2048->1024 level)
-    return forced || blocks >= 128;
+    return true;
 }
+
+static int halo_tiles(const KParams& p) { return p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT; }
+
+// Split-K (SPLIT instantiation): launches with fewer tiles than CUs and at least four 64-channel blocks per
+// split - the 16x16 level of ADM-256 at B = 16 (1024->1024: 128 tiles x 2, 1024->512: 64 tiles x 4).  bf16, whole N-tiles, no
+// GroupNorm prologue; the caller opts in by passing the workspace (nlc_conv2d_workspace_bytes).  tuning bit 7 disables it (A/B).
+int nlc_conv_halo_ksplit(const KParams& p, int dtype) {
+    if (dtype != NLC_BF16 || p.gn_coef || (p.Cout % BN) != 0 || (p.tuning & 128)) return 1;
+    if (!halo_eligible(p, dtype, nullptr)) return 1;
+    const int tiles = halo_tiles(p), ncb = p.Cin_pad / MmaH<bf16_raw>::KBE;
+    if (tiles >= 256) return 1;
+    int ks = 256 / tiles;
+    if (ks > 4) ks = 4;
+    if (ks > ncb / 4) ks = ncb / 4;                  // >= 4 channel blocks (36 k-steps) per split: 256->1024 @16^2 at 2 per split lost 12 %
+    if (ks < 2 || tiles * ks < 128) return 1;
+    return ks;
+}
+
+// the un-split kernel pays from 128 tiles on: at 128-255 (the 16x16 level of ADM-256 at B = 16) half the CUs idle, and it still
+// beats conv_fast + split-K + reduce (1024->1024: 100 vs 114 us, 512->1024: 55 vs 70, 256->1024: 34 vs 52; 2048->1024 level)
+static bool halo_plain_ok(const KParams& p, int dtype) {
+    bool forced = false;
+    if (!halo_eligible(p, dtype, &forced)) return false;
+    return forced || halo_tiles(p) >= 128;
+}
+
+int nlc_conv_halo_plain_ok(const KParams& p, int dtype) { return halo_plain_ok(p, dtype) ? 1 : 0; }
 
 int nlc_conv_halo_prologue_ok(const KParams& p, int dtype) {
     if (p.tuning & 16) return 0;                     // A/B runs: GroupNorm prologue in conv_tall only (tuning bit 4)
-    return dtype == NLC_BF16 && halo_eligible(p, dtype, nullptr) ? 1 : 0;
+    return dtype == NLC_BF16 && halo_plain_ok(p, dtype) ? 1 : 0;
 }
 
-// GroupNorm statistics ride along when the halo kernel runs in bf16 with NHWC output and whole 128-channel N-tiles
+// GroupNorm statistics ride along when the halo kernel runs in bf16 with NHWC output and whole 128-channel N-tiles: four partials
+// per 16x16 patch (split-K launches too: from the epilogue of the workgroup that arrives last at the tile)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
     if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
-    if (!halo_eligible(p, dtype, nullptr)) return 0;
+    if (nlc_conv_halo_ksplit(p, dtype) <= 1 && !halo_plain_ok(p, dtype)) return 0;
     return (p.Hout / PATCH) * (p.Wout / PATCH) * 4;
 }
 
 // 3x3 / stride 1 / pad 1 (optionally on the nearest-2x upsampled input), output H and W multiples of 16, enough tiles to fill the chip.
 // nlc_conv_desc.policy: NLC_CONV_NO_HALO disables, NLC_CONV_FORCE_HALO forces (for eligible shapes) regardless of the tile count.
+// p.ksplit > 1 (set by nlc_conv2d when nlc_conv_halo_ksplit asks for it and the caller passed the workspace): split-K + reduce.
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
-    if (!halo_eligible(p, dtype, nullptr)) return NLC_EUNSUPPORTED;
+    if (p.ksplit > 1) {
+        if (nlc_conv_halo_ksplit(p, dtype) != p.ksplit || !p.partial) return NLC_EUNSUPPORTED;
+        // arrival counters (one int per tile, < 256) behind the partial sums; the kernel leaves them zero, but the workspace is the
+        // caller's and may have been used for something else in between
+        (void)hipMemsetAsync(p.partial + (int64_t)p.ksplit * p.M * p.Cout, 0, 256 * sizeof(int), stream);
+        return launch_halo<bf16_raw, false, true>(p, stream);
+    }
+    if (!halo_plain_ok(p, dtype)) return NLC_EUNSUPPORTED;
     if (dtype == NLC_BF16) return p.gn_coef ? launch_halo<bf16_raw, true>(p, stream) : launch_halo<bf16_raw, false>(p, stream);
     return launch_halo<float, false>(p, stream);
 }

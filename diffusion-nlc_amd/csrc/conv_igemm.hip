@@ -233,18 +233,6 @@ extern "C" int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult) {
     return NLC_OK;
 }
 
-extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype) {
-    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
-    KParams p{};
-    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Cout = d->Cout;
-    p.Cin_pad = d->Cin_pad; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.B = d->B;
-    p.ups = d->upsample2x ? 1 : 0;
-    const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
-    p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
-    const int ks = nlc_conv_fast_ksplit(p, dtype);
-    return ks > 1 ? (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) : 0;
-}
-
 static void geometry_only(const nlc_conv_desc* d, KParams& p) {
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Cout = d->Cout;
     p.Cin_pad = d->Cin_pad; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.B = d->B;
@@ -253,6 +241,19 @@ static void geometry_only(const nlc_conv_desc* d, KParams& p) {
     p.act = d->act; p.bias = d->bias; p.emb = d->emb; p.emb_stride = d->emb_stride; p.gn_coef = d->gn_coef;    // kernel choice looks at these
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
+}
+
+extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype) {
+    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
+    KParams p{};
+    geometry_only(d, p);
+    const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
+    int ks = 1;
+    if (d->policy != NLC_CONV_GENERIC) {
+        if (nlc_conv_tall_stats_partials(p, dtype) == 0 && nlc_conv_wide_stats_partials(p, dtype) == 0) ks = nlc_conv_halo_ksplit(p, dtype);
+        if (ks <= 1) ks = nlc_conv_fast_ksplit(p, dtype);
+    }
+    return ks > 1 ? (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) + 1024 : 0;      // + arrival counters of the halo kernel's split-K
 }
 
 extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
@@ -347,8 +348,15 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         if (rc != NLC_EUNSUPPORTED) return rc;
         rc = nlc_conv_wide_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
+        const int hks = nlc_conv_halo_ksplit(p, dtype);
+        if (hks > 1 && d->workspace && d->workspace_bytes >= (int64_t)hks * p.M * p.Cout * (int64_t)sizeof(float) + 1024) {
+            p.ksplit = hks; p.partial = (float*)d->workspace;
+        } else {
+            NLC_REQUIRE(hks <= 1 || !d->stats_out || nlc_conv_halo_plain_ok(p, dtype), "nlc_conv2d: stats_out on a split-K shape needs the workspace of nlc_conv2d_workspace_bytes");
+        }
         rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
+        p.ksplit = 1; p.partial = nullptr;
         if (!Pfast) { p.stats = nullptr; p.stats_P = 0; }
         if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace
             const int ks = nlc_conv_fast_ksplit(p, dtype);

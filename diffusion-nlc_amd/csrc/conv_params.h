@@ -47,7 +47,10 @@ __device__ __forceinline__ int64_t res_row_m(const KParams& p, int64_t m) {
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);
 // split-K policy for the shapes conv_fast takes (few output tiles, long K): number of splits, 1 = none
 int nlc_conv_fast_ksplit(const KParams& p, int dtype);
-int nlc_conv_fast_stages(const KParams& p);
+int nlc_conv_splitk_reduce(const KParams& p, int dtype, hipStream_t stream);     // conv_fast.hip: reduce + epilogue over p.partial
+// conv_halo.hip: split-K factor of the halo kernel for this launch (1 = none): fewer tiles than CUs, long K, bf16, Cout % 128 == 0
+int nlc_conv_halo_ksplit(const KParams& p, int dtype);
+int nlc_conv_halo_plain_ok(const KParams& p, int dtype);          // the un-split halo kernel would take this launch
 // conv_fast.hip: same for the fast path (0 when K would be split or a tile could straddle two images)
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: partials per image the halo kernel would emit GroupNorm statistics with for this launch (0: it would not)

@@ -588,6 +588,74 @@ def test_groupnorm_coef_then_conv_equals_groupnorm_then_conv():
     assert getattr(fused, "_nlc_stats", None) is not None and err <= 1e-2 * scale, (err, scale)
 
 
+HALOSPLIT_CASES = [
+    dict(B=16, Cin=512, H=16, W=16, Cout=1024, ks=2, res=True, emb=True),                 # 128 tiles x 2: the ADM-256 16x16 level at B = 16
+    dict(B=16, Cin=1024, H=16, W=16, Cout=512, ks=4, split=512, res=True),                # 64 tiles x 4; the concat boundary coincides with a split boundary
+    dict(B=4, Cin=768, H=32, W=32, Cout=512, ks=3, split=256, scale=math.sqrt(0.5)),      # 64 tiles x 3 (12 channel blocks), a split starts at the second segment
+    dict(B=16, Cin=512, H=16, W=16, Cout=1024, ks=2, split=64),                           # the concat boundary lies INSIDE the first split
+    dict(B=16, Cin=512, H=16, W=16, Cout=1024, ks=2, ups_from=(8, 8), res=True),          # fused nearest-2x upsample
+    dict(B=8, Cin=256, H=16, W=32, Cout=256, ks=2, ups_from=(8, 16)),                     # fused nearest-2x upsample, 32 tiles... x 2 = 64 < 128: NOT split
+]
+
+
+@pytest.mark.parametrize("case", HALOSPLIT_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_halo_kernel_split_k(case):
+    """conv_halo_kernel<bf16, false, SPLIT> under the production dispatch: launches with fewer tiles than CUs; raw f32 partial sums per
+    channel-block range, reduced in split order by whichever workgroup arrives last at the tile, which then runs the normal epilogue
+    (bias / embedding / residual / statistics).  Deterministic: two runs are bit-identical."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(47)
+    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
+    ups = "ups_from" in case
+    if ups:
+        H, W = case["ups_from"]
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    xr = _rt(x, torch.bfloat16)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups else xr
+    ref = F.conv2d(xin, _rt(w, torch.bfloat16), b, padding=1)
+    emb = res = None
+    if case.get("emb"):
+        emb = torch.randn(B, Cout, generator=g)
+        ref = ref + emb[:, :, None, None]
+    if case.get("res"):
+        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
+        ref = ref + _rt(res, torch.bfloat16)
+    ref = ref * case.get("scale", 1.0)
+    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    split = case.get("split")
+    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
+    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
+    kw = dict(x1=x1, upsample2x=ups, emb=None if emb is None else emb.to(_dev()), res=None if res is None else _nhwc(res, torch.bfloat16),
+              out_scale=case.get("scale", 1.0))
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "auto"
+    try:
+        got = ops.conv2d(x0, pw, **kw)
+        again = ops.conv2d(x0, pw, **kw)
+        assert torch.equal(got, again)               # fixed summation order whoever arrives last
+        ops.CONV_TUNING = 128                        # the same launch without the halo kernel's split-K
+        plain = ops.conv2d(x0, pw, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_POLICY = old
+        ops.CONV_TUNING = 0
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    st = getattr(got, "_nlc_stats", None)
+    tiles = B * (Ho // 16) * (Wo // 16) * (Cout // 128)
+    if tiles * case["ks"] >= 128:
+        assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 16) * 4, Cout // 8, 2), "the halo kernel did not take this launch"
+    _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (halo split-K)")
+    assert (got.float() - plain.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    if st is not None:
+        ch = got.float().cpu().view(B, Ho * Wo, Cout // 8, 8).double()
+        tot = st.double().sum(dim=1).cpu()
+        s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
+        assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
+        assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3
+
+
 RESUPS_CASES = [
     # (B, Cin, H, W, Cout, policy, dtype): every kernel family that reads a residual
     (2, 64, 32, 32, 128, "halo", torch.bfloat16),        # halo kernel, hot epilogue
