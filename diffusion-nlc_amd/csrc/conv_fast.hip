@@ -226,28 +226,61 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     // ---- after the k-loop lane (fr, fq) of wave (wm, wn) holds, for the 4 pixels m0 + wm*64 + i*16 + fr, the 16
     //      consecutive output channels n0 + wn*64 + fq*16 + [0, 16): acc[i][j][reg] -> channel offset j*4 + reg
     const int n = n0 + wn * 64 + fq * 16;
-    if (n >= p.Cout) return;
     const bool all16 = n + 16 <= p.Cout;
 
-    // ---- split-K: raw f32 partial sums, [split][M][Cout]; bias / embedding / residual / activation are applied by
-    //      splitk_reduce_kernel, which adds the splits in a fixed order (deterministic)
+    // ---- split-K: every workgroup of a tile writes its accumulators as raw f32 partial sums, laid out
+    //      [split][tile][wave][accumulator register 0..63][lane] (a wave-instruction moves 256 contiguous bytes); the workgroup that
+    //      ARRIVES LAST at the tile (one self-resetting counter per tile) reads all of the tile's partials back in split order - a
+    //      fixed summation order whoever is last - and runs the normal epilogue below.  The partials cross workgroups on different
+    //      XCDs (one L2 each) through relaxed AGENT-scope atomic accesses ordered by the counter; no release fence (it writes
+    //      back the XCD's whole dirty L2) and no separate reduce launch (conv_halo.hip has the same scheme).
     if (p.ksplit > 1) {
-        float* part = p.partial + (int64_t)blockIdx.y * p.M * p.Cout;
+        __shared__ int s_last;
+        const int ks = p.ksplit;
+        auto pbase = [&](int sp) { return p.partial + ((((int64_t)sp * nblk + bid) * 4 + wave) * 64) * 64 + lane; };
+        {
+            float* pp = pbase(blockIdx.y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __hip_atomic_store(pp + (i * 16 + j * 4 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's partial stores have been acknowledged ...
+        __syncthreads();                                             // ... and every lane's, before the arrival is counted
+        if (tid == 0) {
+            int* cnt = reinterpret_cast<int*>(p.partial + (int64_t)ks * nblk * (BM * BN)) + bid;
+            const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == ks - 1;
+            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-resetting
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;                                         // workgroup-uniform
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + fr;
-            if (m >= p.M) continue;
-            float* dst = part + (int64_t)m * p.Cout + n;
-            if (all16) {                                     // ksplit > 1 implies Cout % 4 == 0: 16-byte aligned
 #pragma unroll
-                for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(dst + j * 4) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            } else {
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < ks; s0 += 2) {                     // two splits' loads at a time, adds in split order
+                float tmp[2][16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) if (n + k < p.Cout) dst[k] = acc[i][k >> 2][k & 3];
+                for (int u = 0; u < 2; ++u) {
+                    const float* pp = pbase(s0 + u < ks ? s0 + u : 0) + i * 16 * 64;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        tmp[u][k] = s0 + u < ks ? __hip_atomic_load(pp + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + tmp[0][j * 4 + r]) + tmp[1][j * 4 + r];     // + 0.f past ks: exact
             }
         }
-        return;
     }
+    if (n >= p.Cout) return;
+    const bool pix_stats = p.ksplit > 1;             // split launches emit one statistics partial per PIXEL (tiles may straddle images)
 
     // ---- epilogue straight from registers
     const bool vec_ok = (p.Cout % PER) == 0;
@@ -307,10 +340,16 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                 if (has_stats) {         // of the STORED (bf16-rounded) values - what the GroupNorm that follows reads
                     float sv[16];
                     chunk_to_f32<T>(pk0, sv); chunk_to_f32<T>(pk1, sv + 8);
+                    if (pix_stats) { gsum[0] = gsum[1] = gsq[0] = gsq[1] = 0.f; }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         gsum[0] += sv[k]; gsq[0] = fmaf(sv[k], sv[k], gsq[0]);
                         gsum[1] += sv[8 + k]; gsq[1] = fmaf(sv[8 + k], sv[8 + k], gsq[1]);
+                    }
+                    if (pix_stats) {     // [b][pixel][chunk][{sum, sumsq}], stats_P = Hout * Wout
+                        const int b = m / HWo;
+                        float* dst = p.stats + (((int64_t)b * p.stats_P + (m - b * HWo)) * (p.Cout >> 3) + (n >> 3)) * 2;
+                        *reinterpret_cast<float4*>(dst) = float4{gsum[0], gsq[0], gsum[1], gsq[1]};
                     }
                 }
             }
@@ -363,6 +402,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                     if constexpr (sizeof(T) == 2) {
                         if (p.stats) {
                             const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+                            if (pix_stats) { gsum[c] = 0.f; gsq[c] = 0.f; }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float lo = __uint_as_float(wds[q] << 16), hi = __uint_as_float(wds[q] & 0xffff0000u);
@@ -370,6 +410,12 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                                 gsq[c] = fmaf(lo, lo, gsq[c]); gsq[c] = fmaf(hi, hi, gsq[c]);
                             }
                         }
+                    }
+                }
+                if constexpr (sizeof(T) == 2) {
+                    if (p.stats && pix_stats) {
+                        float* dst = p.stats + (((int64_t)b * p.stats_P + (m - b * HWo)) * (p.Cout >> 3) + (n >> 3)) * 2;
+                        *reinterpret_cast<float4*>(dst) = float4{gsum[0], gsq[0], gsum[1], gsq[1]};
                     }
                 }
             } else {
@@ -384,7 +430,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (p.stats) {       // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
+        if (p.stats && !pix_stats) {       // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
             // sum over the 16 pixel lanes of a DPP row, VALU only (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
             auto row16_sum = [](float x) {
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
@@ -404,60 +450,6 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     }
 }
 
-// out[m][n] = act((sum_s partial[s][m][n] + bias[n] + emb[b][n] + res[m][n]) * out_scale), 4 channels per thread
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams p) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;      // quad index
-    const int nq = p.Cout >> 2;
-    if (q >= (int64_t)p.M * nq) return;
-    const int64_t m = q / nq;
-    const int n = (int)(q - m * nq) * 4;
-    const int64_t off = m * p.Cout + n;
-    float4 v = *reinterpret_cast<const float4*>(p.partial + off);
-    for (int s = 1; s < p.ksplit; ++s) {
-        const float4 t = *reinterpret_cast<const float4*>(p.partial + (int64_t)s * p.M * p.Cout + off);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
-    float r[4] = {v.x, v.y, v.z, v.w};
-    const int64_t roff = res_row_m(p, m) * p.Cout + n;
-    const int HWo = p.Hout * p.Wout;
-    const int b = (int)(m / HWo);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float x = r[k];
-        if (p.bias) x += p.bias[n + k];
-        if (p.emb) x += p.emb[(int64_t)b * p.emb_stride + n + k];
-        if (p.res) x += ElemTraits<T>::load(reinterpret_cast<const T*>(p.res) + roff + k);
-        r[k] = apply_act(x * p.out_scale, p.act);
-    }
-    if (p.out_mode == NLC_OUT_NHWC) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ElemTraits<T>::store(reinterpret_cast<T*>(p.out) + off + k, r[k]);
-        if constexpr (sizeof(T) == 2) {
-            if (p.stats) {
-                // GroupNorm statistics ride along here too (the 16x16 / 8x8 levels): two neighbouring threads hold one
-                // 8-channel chunk of one pixel; one partial per pixel (stats_P = Hout * Wout), dispatch: Cout % 8 == 0
-                float q[4];                            // the STORED (bf16-rounded) values, as everywhere else
-#pragma unroll
-                for (int k = 0; k < 4; ++k) q[k] = bf16_to_f32(f32_to_bf16(r[k]));
-                float s1 = (q[0] + q[1]) + (q[2] + q[3]);
-                float s2 = fmaf(q[0], q[0], fmaf(q[1], q[1], fmaf(q[2], q[2], q[3] * q[3])));
-                s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, false));
-                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0xB1, 0xf, 0xf, false));
-                if (((n >> 2) & 1) == 0) {
-                    const int64_t pix = m - (int64_t)b * HWo;
-                    float* dst = p.stats + (((int64_t)b * p.stats_P + pix) * (p.Cout >> 3) + (n >> 3)) * 2;
-                    *reinterpret_cast<float2*>(dst) = float2{s1, s2};
-                }
-            }
-        }
-    } else {
-        const int64_t rem = m - (int64_t)b * HWo;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) reinterpret_cast<float*>(p.out)[((int64_t)b * p.Cout + n + k) * HWo + rem] = r[k];
-    }
-}
-
 template <typename T, int TAPS, int STAGES>
 int launch_fast(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
@@ -465,11 +457,9 @@ int launch_fast(const KParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   STAGES * STAGE_BYTES);
     });
+    if (p.ksplit > 1)    // arrival counters behind the partial sums: the kernel leaves them zero, but the workspace is the caller's
+        (void)hipMemsetAsync(p.partial + (int64_t)p.ksplit * p.MT * p.NT * (BM * BN), 0, 4096, stream);
     hipLaunchKernelGGL((conv_fast_kernel<T, TAPS, STAGES>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), STAGES * STAGE_BYTES, stream, p);
-    if (p.ksplit > 1) {
-        const int64_t quads = (int64_t)p.M * (p.Cout >> 2);
-        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, stream, p);
-    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(fast): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
@@ -505,23 +495,18 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
 }
 
 // GroupNorm statistics ride along on the fast path when the N-tiles are whole and the output is bf16 NHWC: from the conv
-// epilogue if every 128-pixel tile lies inside one image, from the split-K reduce kernel when K is split
+// epilogue if every 128-pixel tile lies inside one image, per pixel from the last-arriving workgroup when K is split
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
     if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0 || !fast_shape(p)) return 0;
     const int HWo = p.Hout * p.Wout;
-    if (nlc_conv_fast_ksplit(p, dtype) > 1) return HWo;          // split-K: the reduce kernel emits one partial per pixel
+    if (nlc_conv_fast_ksplit(p, dtype) > 1) return HWo;          // split-K: the last-arriving workgroup emits one partial per pixel
     if (HWo % BM) return 0;
     return (HWo / BM) * 2;
 }
 
-// the reduce + epilogue pass over [ksplit][M][Cout] f32 partial sums (p.partial, p.ksplit), also for the halo kernel's split-K launches
-int nlc_conv_splitk_reduce(const KParams& p, int dtype, hipStream_t stream) {
-    const int64_t quads = (int64_t)p.M * (p.Cout >> 2);
-    if (dtype == NLC_BF16) hipLaunchKernelGGL((splitk_reduce_kernel<bf16_raw>), dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)cdiv(quads, 256)), dim3(256), 0, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { nlc_set_error("nlc_conv2d(split-K reduce): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
-    return NLC_OK;
+// workspace of a split launch: ks x (whole 128 x 128 tiles) f32 partial sums + the arrival counters (tiles < 512)
+int64_t nlc_conv_fast_split_bytes(const KParams& p, int ks) {
+    return ks > 1 ? (int64_t)ks * p.MT * p.NT * (BM * BN) * (int64_t)sizeof(float) + 4096 : 0;
 }
 
 // returns NLC_EUNSUPPORTED when the shape is not one the fast path handles (caller falls back)

@@ -248,12 +248,11 @@ extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype)
     KParams p{};
     geometry_only(d, p);
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
+    if (d->policy == NLC_CONV_GENERIC) return 0;
     int ks = 1;
-    if (d->policy != NLC_CONV_GENERIC) {
-        if (nlc_conv_tall_stats_partials(p, dtype) == 0 && nlc_conv_wide_stats_partials(p, dtype) == 0) ks = nlc_conv_halo_ksplit(p, dtype);
-        if (ks <= 1) ks = nlc_conv_fast_ksplit(p, dtype);
-    }
-    return ks > 1 ? (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) + 1024 : 0;      // + arrival counters of the halo kernel's split-K
+    if (nlc_conv_tall_stats_partials(p, dtype) == 0 && nlc_conv_wide_stats_partials(p, dtype) == 0) ks = nlc_conv_halo_ksplit(p, dtype);
+    if (ks > 1) return (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) + 1024;      // + arrival counters of the halo kernel's split-K
+    return nlc_conv_fast_split_bytes(p, nlc_conv_fast_ksplit(p, dtype));
 }
 
 extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
@@ -360,7 +359,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         if (!Pfast) { p.stats = nullptr; p.stats_P = 0; }
         if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace
             const int ks = nlc_conv_fast_ksplit(p, dtype);
-            if (ks > 1 && d->workspace_bytes >= (int64_t)ks * p.M * p.Cout * (int64_t)sizeof(float)) {
+            if (ks > 1 && d->workspace_bytes >= nlc_conv_fast_split_bytes(p, ks)) {
                 p.ksplit = ks; p.partial = (float*)d->workspace;
             }
         }

@@ -22,7 +22,7 @@ struct KParams {
     char* out; int out_mode;
     int M, MT, NT;
     int ksplit;         // conv_fast only: >1 = split the channel blocks over blockIdx.y, raw f32 partials to `partial`
-    float* partial;     // [ksplit][M][Cout] f32 (caller workspace); reduced + epilogue by splitk_reduce_kernel
+    float* partial;     // split-K partial sums + arrival counters (caller workspace); reduced by the last-arriving workgroup of a tile
     float* stats;       // conv_halo / conv_fast (bf16, NHWC out, Cout % 128 == 0) or NULL: [B][stats_P][Cout/8][2] = per 8-channel
     int stats_P;        //   chunk (sum, sum of squares) of the STORED (bf16-rounded) outputs, one partial per (patch, M-wave)
     int policy;         // NLC_CONV_* kernel-selection policy of this call (nlc_conv_desc.policy)
@@ -47,7 +47,7 @@ __device__ __forceinline__ int64_t res_row_m(const KParams& p, int64_t m) {
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream);
 // split-K policy for the shapes conv_fast takes (few output tiles, long K): number of splits, 1 = none
 int nlc_conv_fast_ksplit(const KParams& p, int dtype);
-int nlc_conv_splitk_reduce(const KParams& p, int dtype, hipStream_t stream);     // conv_fast.hip: reduce + epilogue over p.partial
+int64_t nlc_conv_fast_split_bytes(const KParams& p, int ks);     // workspace bytes of a conv_fast launch split ks ways
 // conv_halo.hip: split-K factor of the halo kernel for this launch (1 = none): fewer tiles than CUs, long K, bf16, Cout % 128 == 0
 int nlc_conv_halo_ksplit(const KParams& p, int dtype);
 int nlc_conv_halo_plain_ok(const KParams& p, int dtype);          // the un-split halo kernel would take this launch
