@@ -465,7 +465,7 @@ def roofline_leg(wl, x, dtype, args):
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
     peak = PEAK_BF16_DENSE_TFLOPS if dtype == torch.bfloat16 else 157.3
     out = {"bound": "mfma",
-           "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3 on >= 32x32 maps) + conv_fast_kernel<{args.dtype},9|1> (+ splitk_reduce) + conv_igemm_kernel",
+           "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3, >= 64 tiles) + conv_fast_kernel<{args.dtype},9|1> + conv_igemm_kernel",
            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
            "avg_launch_us": 1e3 * tot_ms / max(n, 1), "avg_launch_gflop": tot_fl / max(n, 1) / 1e9,
            "share_of_step": tot_ms * 1e-3 / wall, "measured": "HIP events around every conv launch of one extra (untimed) step"}
