@@ -237,7 +237,8 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     if (p.ksplit > 1) {
         __shared__ int s_last;
         const int ks = p.ksplit;
-        auto pbase = [&](int sp) { return p.partial + ((((int64_t)sp * nblk + bid) * 4 + wave) * 64) * 64 + lane; };
+        // workspace = [1024 arrival counters][partial sums]: the counters sit in FRONT so that no launch's partials ever cover them
+        auto pbase = [&](int sp) { return p.partial + 1024 + ((((int64_t)sp * nblk + bid) * 4 + wave) * 64) * 64 + lane; };
         {
             float* pp = pbase(blockIdx.y);
 #pragma unroll
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's partial stores have been acknowledged ...
         __syncthreads();                                             // ... and every lane's, before the arrival is counted
         if (tid == 0) {
-            int* cnt = reinterpret_cast<int*>(p.partial + (int64_t)ks * nblk * (BM * BN)) + bid;
+            int* cnt = reinterpret_cast<int*>(p.partial) + bid;
             const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = old == ks - 1;
             if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-resetting
@@ -457,8 +458,6 @@ int launch_fast(const KParams& p, hipStream_t stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   STAGES * STAGE_BYTES);
     });
-    if (p.ksplit > 1)    // arrival counters behind the partial sums: the kernel leaves them zero, but the workspace is the caller's
-        (void)hipMemsetAsync(p.partial + (int64_t)p.ksplit * p.MT * p.NT * (BM * BN), 0, 4096, stream);
     hipLaunchKernelGGL((conv_fast_kernel<T, TAPS, STAGES>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), STAGES * STAGE_BYTES, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(fast): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
@@ -504,7 +503,7 @@ int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
     return (HWo / BM) * 2;
 }
 
-// workspace of a split launch: ks x (whole 128 x 128 tiles) f32 partial sums + the arrival counters (tiles < 512)
+// workspace of a split launch: the arrival counters (4 KiB in front; tiles < 512) + ks x (whole 128 x 128 tiles) f32 partial sums
 int64_t nlc_conv_fast_split_bytes(const KParams& p, int ks) {
     return ks > 1 ? (int64_t)ks * p.MT * p.NT * (BM * BN) * (int64_t)sizeof(float) + 4096 : 0;
 }

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             // [M][Cout] layout every lane of a dword access touched a cache line of its own: +130 us per launch), and the last
             // arriver's lane (wave, lane) finds exactly its own elements at its own offset.  Same size: 256 x 128 floats per tile.
             const int ntile = nblk / ksp;
-            auto pbase = [&](int sp) { return p.partial + ((((int64_t)sp * ntile + t.tix) * 8 + wave) * 64) * 64 + lane; };
+            auto pbase = [&](int sp) { return p.partial + 1024 + ((((int64_t)sp * ntile + t.tix) * 8 + wave) * 64) * 64 + lane; };     // [1024 counters][partials]
             {
                 float* pp = pbase(t.ks);
 #pragma unroll
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this lane's partial stores have been acknowledged ...
             __syncthreads();                         // ... and every lane's, before the workgroup's arrival is counted
             if (tid == 0) {
-                int* cnt = reinterpret_cast<int*>(p.partial + (int64_t)ksp * p.M * p.Cout) + t.tix;
+                int* cnt = reinterpret_cast<int*>(p.partial) + t.tix;
                 const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = old == ksp - 1;
                 if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-resetting
@@ -865,9 +865,6 @@ int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (p.ksplit > 1) {
         if (nlc_conv_halo_ksplit(p, dtype) != p.ksplit || !p.partial) return NLC_EUNSUPPORTED;
-        // arrival counters (one int per tile, < 256) behind the partial sums; the kernel leaves them zero, but the workspace is the
-        // caller's and may have been used for something else in between
-        (void)hipMemsetAsync(p.partial + (int64_t)p.ksplit * p.M * p.Cout, 0, 256 * sizeof(int), stream);
         return launch_halo<bf16_raw, false, true>(p, stream);
     }
     if (!halo_plain_ok(p, dtype)) return NLC_EUNSUPPORTED;

@@ -251,7 +251,7 @@ extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype)
     if (d->policy == NLC_CONV_GENERIC) return 0;
     int ks = 1;
     if (nlc_conv_tall_stats_partials(p, dtype) == 0 && nlc_conv_wide_stats_partials(p, dtype) == 0) ks = nlc_conv_halo_ksplit(p, dtype);
-    if (ks > 1) return (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) + 1024;      // + arrival counters of the halo kernel's split-K
+    if (ks > 1) return (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) + 4096;      // arrival counters in front of the halo kernel's partial sums
     return nlc_conv_fast_split_bytes(p, nlc_conv_fast_ksplit(p, dtype));
 }
 
@@ -348,7 +348,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         rc = nlc_conv_wide_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         const int hks = nlc_conv_halo_ksplit(p, dtype);
-        if (hks > 1 && d->workspace && d->workspace_bytes >= (int64_t)hks * p.M * p.Cout * (int64_t)sizeof(float) + 1024) {
+        if (hks > 1 && d->workspace && d->workspace_bytes >= (int64_t)hks * p.M * p.Cout * (int64_t)sizeof(float) + 4096) {
             p.ksplit = hks; p.partial = (float*)d->workspace;
         } else {
             NLC_REQUIRE(hks <= 1 || !d->stats_out || nlc_conv_halo_plain_ok(p, dtype), "nlc_conv2d: stats_out on a split-K shape needs the workspace of nlc_conv2d_workspace_bytes");

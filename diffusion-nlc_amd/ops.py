@@ -265,11 +265,12 @@ FUSED_GN_STATS = True        # groupnorm() uses statistics emitted by the produc
 
 
 def _conv_workspace(device, nbytes: int) -> torch.Tensor:
-    """Per (device, stream) scratch for nlc_conv2d's split-K partials; grows to the largest request."""
+    """Per (device, stream) scratch for nlc_conv2d's split-K partials; grows to the largest request.  Allocated ZEROED: its first
+    4 KiB are the library's arrival counters, which every launch leaves zero (include/nlc_hip.h, nlc_conv_desc.workspace)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(nbytes // 4 + 1, device=device, dtype=torch.float32)
+        ws = torch.zeros(nbytes // 4 + 1, device=device, dtype=torch.float32)
         _conv_ws[key] = ws
     return ws
 

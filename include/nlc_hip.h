@@ -113,7 +113,9 @@ typedef struct nlc_conv_desc {
     void* out;           /* NLC_OUT_NHWC: compute dtype; NLC_OUT_NCHW_F32: float */
     int32_t out_mode;
     void* workspace;     /* optional scratch (NULL = none): enables split-K on shapes with few output tiles and a long */
-    int64_t workspace_bytes; /* K (the 8x8 / 16x16 levels); size from nlc_conv2d_workspace_bytes, contents undefined   */
+    int64_t workspace_bytes; /* K (the 8x8 / 16x16 levels); size from nlc_conv2d_workspace_bytes.  Its FIRST 4096 BYTES are    */
+                         /* the library's arrival counters: zero them once when the buffer is allocated and never write them; */
+                         /* every launch leaves them zero.  The rest is undefined scratch.  One workspace per stream.          */
     void* stats_out;     /* optional (NULL = none): GroupNorm statistics of the output, written by the conv's epilogue so    */
     int64_t stats_bytes; /* that the normalisation that follows (src/unet_adm.py:182-184,206-208) skips its statistics pass: */
                          /* float [B][P][Cout/8][2] = (sum, sum of squares) of the STORED values per 8-channel chunk and     */
