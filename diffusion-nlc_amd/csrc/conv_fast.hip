@@ -264,10 +264,10 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            for (int s0 = 0; s0 < ks; s0 += 2) {                     // two splits' loads at a time, adds in split order
-                float tmp[2][16];
+            for (int s0 = 0; s0 < ks; s0 += 4) {                     // four splits' loads at a time (64 in flight), adds in split order
+                float tmp[4][16];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     const float* pp = pbase(s0 + u < ks ? s0 + u : 0) + i * 16 * 64;
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
@@ -276,7 +276,8 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + tmp[0][j * 4 + r]) + tmp[1][j * 4 + r];     // + 0.f past ks: exact
+                    for (int r = 0; r < 4; ++r)                  // + 0.f past ks: exact
+                        acc[i][j][r] = (((acc[i][j][r] + tmp[0][j * 4 + r]) + tmp[1][j * 4 + r]) + tmp[2][j * 4 + r]) + tmp[3][j * 4 + r];
             }
         }
     }
