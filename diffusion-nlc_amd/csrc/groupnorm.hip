@@ -39,6 +39,7 @@ struct GNParams {
     int silu;
     char* out;
     double* ws;         // [B][nblk][G][3] = (count, mean, M2)
+    const float* coef;  // [B][C][2] = (a, b) per (image, channel), written by gn_finalize_chunks_kernel, or NULL: the apply threads compute them
 };
 
 template <typename T>
@@ -355,6 +356,15 @@ __global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __r
 template <int PER>
 __device__ __forceinline__ void gn_channel_coefs(const GNParams& p, const float* __restrict__ stat, int b, int c0,
                                                  float (&ca)[PER], float (&cb)[PER]) {
+    if (p.coef) {                                    // folded once per (image, channel) by the finalize kernel: 2 PER floats, one round trip
+        const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)b * p.C + c0) * 2);
+#pragma unroll
+        for (int q = 0; q < PER / 2; ++q) {
+            const float4 v = cf[q];                  // a0 b0 a1 b1
+            ca[2 * q] = v.x; cb[2 * q] = v.y; ca[2 * q + 1] = v.z; cb[2 * q + 1] = v.w;
+        }
+        return;
+    }
     float mean = 0.f, rstd = 0.f;
     int gprev = -1;
 #pragma unroll
@@ -502,6 +512,7 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
     p.x0 = (const char*)x0; p.x1 = (const char*)x1;
     p.C0 = C0; p.C1 = C1; p.C = C0 + C1; p.B = B; p.HW = HW; p.G = groups; p.gs = p.C / groups;
     p.nch = p.C / per;
+    p.coef = nullptr;
     p.tpp = p.nch < NT ? p.nch : NT;
     p.nslot = cdiv(p.nch, p.tpp);
     p.ps = NT / p.tpp; if (p.ps < 1) p.ps = 1;
@@ -530,8 +541,9 @@ static int apply_pix_per_block(int HW, int B, int ps, int unit) {
 }
 
 extern "C" int64_t nlc_groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
-    (void)HW; (void)C;
-    return (int64_t)B * MAX_NBLK * groups * 3 * sizeof(double) + (int64_t)B * groups * 2 * sizeof(float);
+    (void)HW;
+    return (int64_t)B * MAX_NBLK * groups * 3 * sizeof(double) + (int64_t)B * groups * 2 * sizeof(float) + 16 +
+           (int64_t)B * C * 2 * sizeof(float);      // + the per-(image, channel) coefficient table of the ride-along-statistics path
 }
 
 extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, float eps,
@@ -612,8 +624,14 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     hipStream_t st = (hipStream_t)stream;
     float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
     const int ppb = apply_pix_per_block(HW, B, p.ps, p.ps * UNR * 4);
+    // the finalize kernel also folds gamma / beta / FiLM into one (a, b) pair per (image, channel): the apply threads then start
+    // with four 16-byte loads instead of five scalar loads and the algebra per channel
+    float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
-                       eps, stat, GNCoefOut{});
+                       eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride});
+#ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
+    p.coef = coef;
+#endif
     hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb);
     NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
     return NLC_OK;
@@ -641,8 +659,12 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
     hipStream_t st = (hipStream_t)stream;
     float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
     if (stats0) {
+        float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
         hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
-                           groups, HW, eps, stat, GNCoefOut{});
+                           groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride});
+    #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
+    p.coef = coef;
+#endif
     } else {
         const size_t lds_stats = (size_t)p.ps * p.C * 3 * sizeof(float);
         NLC_REQUIRE(lds_stats <= 64 * 1024, "nlc_groupnorm_pool2x2: LDS budget exceeded (C=%d)", C);
