@@ -656,6 +656,28 @@ def test_conv2d_halo_kernel_split_k(case):
         assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3
 
 
+def test_split_k_launches_leave_the_arrival_counters_zero():
+    """nlc_conv_desc.workspace: the first 4096 bytes are the split-K arrival counters (one per tile, self-resetting); a sequence of
+    split launches of different shapes and kernels through ONE workspace leaves them zero and every result right."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(53)
+    shapes = [(16, 512, 16, 16, 1024, 3), (16, 1024, 8, 8, 1024, 3), (16, 1024, 8, 8, 3072, 1), (16, 1024, 16, 16, 512, 3), (16, 512, 16, 16, 1024, 3)]
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "auto"
+    try:
+        for B, Cin, H, W, Cout, k in shapes:
+            x = torch.randn(B, Cin, H, W, generator=g)
+            w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+            got = ops.conv2d(_nhwc(x, torch.bfloat16), ops.pack_conv(w, None, torch.bfloat16, _dev()))
+            ref = F.conv2d(_rt(x, torch.bfloat16), _rt(w, torch.bfloat16), None, padding=k // 2)
+            _close(got.permute(0, 3, 1, 2), ref, 2e-2, f"split-K sequence {Cin}->{Cout} @{H}")
+            torch.cuda.synchronize()
+            ws = [t for t in ops._conv_ws.values() if t.device == got.device]
+            assert ws and all(int(t[:1024].view(torch.int32).abs().max().item()) == 0 for t in ws), "arrival counters not left zero"
+    finally:
+        ops.CONV_POLICY = old
+
+
 RESUPS_CASES = [
     # (B, Cin, H, W, Cout, policy, dtype): every kernel family that reads a residual
     (2, 64, 32, 32, 128, "halo", torch.bfloat16),        # halo kernel, hot epilogue
