@@ -489,7 +489,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     }
                     T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
                     const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
-#ifndef HALO_NO_STORE                                          /* timing diagnostics only (tools/variant.sh conv_halo) */
+#ifndef HALO_NO_STORE                                          /* timing diagnostics only (tools/halo_variant.sh) */
                     *reinterpret_cast<uint4*>(op) = pk0;
                     *reinterpret_cast<uint4*>(op + 8) = pk1;
 #endif
