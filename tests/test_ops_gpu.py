@@ -398,7 +398,7 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
         plain = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=True, x1=y2)
     finally:
         ops.FUSED_GN_STATS = True
-    # split-K shape (8x8 level; not halo-eligible): the statistics come from the reduce kernel, one partial per pixel
+    # split-K shape (8x8 level; not halo-eligible): the statistics come from the last-arriving split workgroup, one partial per pixel
     xs = torch.randn(2, 512, 8, 8, generator=g)
     ws = torch.randn(256, 512, 3, 3, generator=g) / math.sqrt(512 * 9)
     ys = ops.conv2d(_nhwc(xs, torch.bfloat16), ops.pack_conv(ws, b, torch.bfloat16, _dev()))
@@ -417,9 +417,9 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
 
 STAT_CASES = [
     # (B, Cin, H, W, Cout, expected partials per image under the production dispatch, what emits them)
-    (2, 512, 16, 16, 256, 256, "split-K reduce: one partial per pixel"),
-    (1, 1024, 16, 16, 1024, 256, "split-K reduce, the ADM-256 16x16 level"),
-    (2, 256, 32, 32, 128, 1024, "split-K reduce on a 32x32 map"),
+    (2, 512, 16, 16, 256, 256, "split-K (last arriver): one partial per pixel"),
+    (1, 1024, 16, 16, 1024, 256, "split-K (last arriver), the ADM-256 16x16 level"),
+    (2, 256, 32, 32, 128, 1024, "split-K (last arriver) on a 32x32 map"),
     (4, 64, 32, 32, 128, 16, "conv_fast<9> epilogue: two partials per 128-pixel tile"),
     (16, 128, 32, 32, 512, 16, "halo kernel, 256 tiles: four partials per 16x16 patch"),
 ]
@@ -683,7 +683,7 @@ RESUPS_CASES = [
     (2, 64, 32, 32, 128, "halo", torch.bfloat16),        # halo kernel, hot epilogue
     (1, 64, 16, 48, 72, "halo", torch.bfloat16),         # halo kernel, general epilogue (ragged Cout)
     (2, 64, 16, 16, 128, "no_halo", torch.bfloat16),     # conv_fast<9>, hot epilogue
-    (16, 128, 8, 8, 128, "auto", torch.bfloat16),        # conv_fast<9> + split-K reduce
+    (16, 128, 8, 8, 128, "auto", torch.bfloat16),        # conv_fast<9> + split-K (last-arriver reduction)
     (2, 40, 12, 20, 24, "generic", torch.bfloat16),      # generic implicit GEMM
     (2, 64, 32, 64, 128, "wide", torch.bfloat16),
     (2, 64, 32, 32, 256, "tall", torch.bfloat16),
