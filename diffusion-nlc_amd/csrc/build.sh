@@ -6,7 +6,7 @@ root="$(cd "$here/../.." && pwd)"
 out="$here/../libnlc_hip.so"
 mkdir -p "$here/obj"
 pids=()
-for f in abi pack conv_igemm conv_fast conv_halo conv_wide conv_tall groupnorm attention elementwise sampler edm constraint; do
+for f in abi pack conv_igemm conv_fast conv_halo conv_wide conv_tall conv_narrow groupnorm attention elementwise sampler edm constraint; do
   o="$here/obj/$f.o"
   if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/conv_params.h" -nt "$o" ] || [ "$root/include/nlc_hip.h" -nt "$o" ] || [ "$here/build.sh" -nt "$o" ]; then
     extra=""

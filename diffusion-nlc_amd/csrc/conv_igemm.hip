@@ -343,7 +343,9 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         }
         NLC_REQUIRE(!p.gn_coef || nlc_conv_tall_prologue_ok(p, dtype) || nlc_conv_halo_prologue_ok(p, dtype),
                     "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue (ask nlc_conv2d_prologue_supported first)");
-        int rc = nlc_conv_tall_dispatch(p, dtype, (hipStream_t)stream);
+        int rc = nlc_conv_narrow_dispatch(p, dtype, (hipStream_t)stream);
+        if (rc != NLC_EUNSUPPORTED) return rc;
+        rc = nlc_conv_tall_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         rc = nlc_conv_wide_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;

@@ -61,6 +61,9 @@ int nlc_conv_wide_dispatch(const KParams& p, int dtype, hipStream_t stream);
 int nlc_conv_tall_stats_partials(const KParams& p, int dtype);     // conv_tall.hip: 256-pixel x 256-channel tiles
 int nlc_conv_tall_dispatch(const KParams& p, int dtype, hipStream_t stream);
 int nlc_conv_tall_prologue_ok(const KParams& p, int dtype);
+// conv_narrow.hip: 3x3 with at most 16 output channels (the networks' last layer)
+int nlc_conv_narrow_ok(const KParams& p, int dtype);
+int nlc_conv_narrow_dispatch(const KParams& p, int dtype, hipStream_t stream);
 // conv_halo.hip: 1 if the halo kernel would take this launch AND can apply a GroupNorm prologue (bf16)
 int nlc_conv_halo_prologue_ok(const KParams& p, int dtype);
 // conv_halo.hip: 3x3 with the input halo resident in LDS; same return convention

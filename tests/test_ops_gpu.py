@@ -678,6 +678,32 @@ def test_split_k_launches_leave_the_arrival_counters_zero():
         ops.CONV_POLICY = old
 
 
+@pytest.mark.parametrize("cout,nchw,B,H,W,Cin,scale", [(6, True, 2, 64, 128, 128, 1.0), (3, False, 4, 64, 64, 64, 0.5), (16, False, 16, 32, 32, 192, 1.0),
+                                                       (1, True, 16, 32, 32, 64, 1.0), (6, True, 16, 256, 256, 256, 1.0)])    # >= 64 patches each
+def test_conv2d_narrow_output_kernel(cout, nchw, B, H, W, Cin, scale):
+    """conv_narrow_kernel: 3x3 with <= 16 output channels under the production dispatch (the networks' last layer, 256 -> 6 / 128 -> 3):
+    whole halo + all nine taps' weights per channel block in LDS, one barrier per block."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(59 + cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(_rt(x, torch.bfloat16), _rt(w, torch.bfloat16), b, padding=1) * scale
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = "auto"
+    try:
+        pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+        got = ops.conv2d(_nhwc(x, torch.bfloat16), pw, out_nchw_f32=nchw, out_scale=scale)
+        ops.CONV_TUNING = 512                        # the same launch through the kernels that took it before
+        other = ops.conv2d(_nhwc(x, torch.bfloat16), pw, out_nchw_f32=nchw, out_scale=scale)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_POLICY = old
+        ops.CONV_TUNING = 0
+    _close(got if nchw else got.permute(0, 3, 1, 2), ref, 1e-2 if nchw else 2e-2, f"conv2d narrow Cout={cout}")
+    assert (got.float() - other.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 RESUPS_CASES = [
     # (B, Cin, H, W, Cout, policy, dtype): every kernel family that reads a residual
     (2, 64, 32, 32, 128, "halo", torch.bfloat16),        # halo kernel, hot epilogue
