@@ -149,6 +149,9 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         const bool cvalid = cch < p.Ctot;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // rows beyond M are never stored: their LDS rows may hold anything, so a 32-row piece that lies entirely beyond M is
+            // not fetched at all (the M = 16 linears of the embedding MLPs spent half their DMA traffic on zero-page rows)
+            if (TAPS == 1 && STAGES == 2 && m0 + 32 * i >= p.M) continue;        // workgroup-uniform (the counted waits of deeper pipelines assume 8 pieces)
             const bool ok = cvalid && ((vmask[i] >> tap) & 1u);
             const char* ptr = ok ? src + ((int64_t)pix[i][tap] * C + ch) * ES : zero;
             glds16(ptr, a_base + i * 32 * KB_BYTES);
@@ -166,21 +169,42 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // M-tiles (16 rows) of this wave that hold real rows: 4 except in the last M-tile of a launch - and in the M = 16 linears of
+    // the embedding MLPs, where 7 of 8 M-tiles are padding and the exact-f32 MFMAs (1/16 of the bf16 rate) were the bound
+    // (1x1 instantiations only: in the 3x3 ones the second copy of the nine-tap body cost the 8x8 level 28 % - 53 -> 68 us)
+    const int nlive = TAPS == 1 ? min(4, max(0, (p.M - m0 - wm * 64 + 15) >> 4)) : 4;        // wave-uniform
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE_BYTES;
         const char* Bs = As + BM * KB_BYTES;
+        if (TAPS != 1 || nlive == 4) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 fa[4], fb[4];
-            const int chunk = kk * 4 + fq;
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 fa[4], fb[4];
+                const int chunk = kk * 4 + fq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, chunk));
+                for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, chunk));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, chunk));
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, chunk));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<T>::run(fb[j], fa[i], acc[i][j]);   // D[channel][pixel]
+                    for (int j = 0; j < 4; ++j) Mma<T>::run(fb[j], fa[i], acc[i][j]);   // D[channel][pixel]
+            }
+        } else if (TAPS == 1 && nlive > 0) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 fb[4];
+                const int chunk = kk * 4 + fq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, chunk));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i >= nlive) break;
+                    const uint4 fa = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, chunk));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma<T>::run(fb[j], fa, acc[i][j]);
+                }
+            }
         }
     };
 
