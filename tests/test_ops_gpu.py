@@ -704,6 +704,24 @@ def test_conv2d_narrow_output_kernel(cout, nchw, B, H, W, Cin, scale):
     assert (got.float() - other.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+def test_new_entry_points_reject_bad_arguments():
+    """Error behaviour of the entry points added this round: loud, with a message, nothing launched."""
+    from diffusion_nlc_amd import _ext, ops
+    x = torch.randn(1, 6, 6, 64, device=_dev()).to(torch.bfloat16)
+    w = ops.pack_conv(torch.randn(64, 64, 3, 3), None, torch.bfloat16, _dev())
+    with pytest.raises(ValueError):                                  # residual of the wrong size for res_upsample2x
+        ops.conv2d(x, w, res=torch.zeros(1, 6, 6, 64, device=_dev(), dtype=torch.bfloat16), res_upsample2x=True)
+    with pytest.raises(ValueError):                                  # res_upsample2x without a residual
+        ops.conv2d(x, w, res_upsample2x=True)
+    x7 = torch.randn(1, 7, 8, 64, device=_dev()).to(torch.bfloat16)
+    g = torch.ones(64, device=_dev())
+    with pytest.raises(_ext.NlcError):                               # odd height
+        ops.groupnorm_pool2x2(x7, g, g, groups=32, eps=1e-5, silu=True)
+    with pytest.raises(_ext.NlcError):                               # unknown conv policy value through the raw descriptor
+        d = _ext.ConvDesc(policy=99)
+        _ext.check(_ext.load().nlc_conv2d(_ext.C.byref(d), 1, None), "nlc_conv2d")
+
+
 RESUPS_CASES = [
     # (B, Cin, H, W, Cout, policy, dtype): every kernel family that reads a residual
     (2, 64, 32, 32, 128, "halo", torch.bfloat16),        # halo kernel, hot epilogue
