@@ -50,21 +50,35 @@ CELEBAHQ = dict(ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2, 
 GF_PER_IMAGE_STEP = 2239.67 + 580.29 + 3.95          # ADM-256
 GF_EDM_EVAL = 42.38 + 13.76 + 0.25                    # EDM CIFAR-32 SongUNet
 GF_CELEBA_STEP = 497.03 + 135.15 + 0.99               # CelebA-HQ-256 simple UNet
-PEAK_BF16_DENSE_TFLOPS = 2500.0
 SIGMA_OVERRIDES = {"final_mlp.weight": 0.1, "final_mlp.bias": 0.5}
 
 
 # ------------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------------
-def build_models(cfg, device, dtype):
+# --dtype -> (storage / operand type, matrix mode of f32 convolutions)
+PRECISIONS = {"bf16": (torch.bfloat16, "native"), "f16": (torch.float16, "native"), "f32": (torch.float32, "native"),
+              "f32x3": (torch.float32, "f16x3")}
+# dense matrix peak the roofline fraction is priced against (MI355X_MICROARCH.md): 16-bit MFMA 2.5 PF; exact f32 MFMA 157.3 TF;
+# f32x3 = three 16-bit passes per product, so 2.5 PF / 3 of ALGORITHMIC FLOPs is its ceiling
+PEAKS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f32x3": 2500.0 / 3}
+
+
+def set_precision(module, prec):
+    dtype, matmul = prec
+    module.set_compute_dtype(dtype)
+    module.set_matmul(matmul)
+    return module
+
+
+def build_models(cfg, device, prec):
     from diffusion_nlc_amd import script_util
     from diffusion_nlc_amd.filler import fill_state_dict
     eps, sig, fshape = script_util.create_sigma_eps_model(**cfg)
     eps.load_state_dict(fill_state_dict(eps.state_dict(), seed=0))
     sig.load_state_dict(fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES))
-    eps.to(device).set_compute_dtype(dtype)
-    sig.to(device).set_compute_dtype(dtype)
+    set_precision(eps.to(device), prec)
+    set_precision(sig.to(device), prec)
     return eps, sig
 
 
@@ -86,7 +100,7 @@ class AdmWorkload:
     """BASELINE.json configs[1]: ADM UNet 256x256, 50-step DDIM+NLC, batch 16 per GPU (the headline metric)."""
     name = "adm256"
 
-    def __init__(self, args, device, dtype):
+    def __init__(self, args, device, dtype):            # dtype: a PRECISIONS entry
         self.cfg = dict(ADM256)
         if args.tiny:
             self.cfg.update(image_size=64, num_channels=64, channel_mult="1,2,2,4", attention_resolutions="16,8", num_head_channels=32)
@@ -138,10 +152,13 @@ class AdmWorkload:
         def one_timestep(x, ind):
             eps, lv, st, sp = o.get_denoise_vector(x, s.timesteps[ind], s.sampling_sigmas[ind], s.sampling_sigmas[ind + 1], "pred", True, True)
             x0 = o.clip(s.pred_xstart(x, eps, st))
+            self.oracle_trace["x0"].append(x0.clone())
+            self.oracle_trace["sigma"].append(st.clone())
             return s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=x, log_variance=lv)
 
         # bounded sample: keep stepping the real trajectory until ~15 s of CPU work (at most 20 of the 50 timesteps)
         n, t0 = 0, time.perf_counter()
+        self.oracle_trace = {"xT": xt.clone(), "x0": [], "sigma": []}       # for parity(): the SAME seeded image on the HIP path
         with torch.no_grad():
             while n < 20 and (n == 0 or time.perf_counter() - t0 < 15.0):
                 xt = one_timestep(xt, n)
@@ -149,6 +166,29 @@ class AdmWorkload:
         dt = (time.perf_counter() - t0) / n
         return {"value": 1.0 / (50.0 * dt), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": f"{n} DDIM+NLC timestep(s) of ADM-{res} at B=1 in f32 on the host ({dt:.2f} s each), extrapolated to 50 timesteps"}
+
+    def parity(self, dtype_name):
+        """BASELINE.json's metric is "images/sec ...; per-pixel L-inf vs CPU ref": the HIP path in the BENCHMARKED precision on the
+        oracle leg's own seeded x_T (B = 1), compared timestep by timestep with what the oracle computed there.  `linf` / `rms`:
+        the sample the loop would return after the last compared timestep (the clipped x0 estimate, in [-1, 1]); `sigma_rel`:
+        the NLC-corrected sigma of that timestep."""
+        tr = getattr(self, "oracle_trace", None)
+        if not tr or not tr["x0"]:
+            return None
+        n = len(tr["x0"])
+        shape = (1, 3, self.res, self.res)
+        exp = self.exp
+        _, logs = exp.denoise_loop(shape=shape, xT=tr["xT"], style="pred", norm_eps=True, refine_prior_sigma=True, return_log=True,
+                                   chunk_size=1, sigma_pred_threshold=960, max_steps=n)
+        x0s, sig = logs[3], exp.sigma_trace
+        per_step = [float((x0s[i].double() - tr["x0"][i].double()).abs().max()) for i in range(n)]
+        d = x0s[n - 1].double() - tr["x0"][n - 1].double()
+        srel = [float(((sig[i].double().view(-1) - tr["sigma"][i].double().view(-1)).abs() / tr["sigma"][i].double().view(-1)).max()) for i in range(n)]
+        return {"dtype": dtype_name, "timesteps": n, "linf": per_step[-1], "rms": float(d.pow(2).mean().sqrt()),
+                "sigma_rel": srel[-1], "linf_first_timestep": per_step[0], "linf_max_over_timesteps": max(per_step),
+                "sigma_rel_max_over_timesteps": max(srel),
+                "what": "HIP path at B=1 on the cpu_baseline leg's seeded x_T vs the CPU oracle (f32), clipped x0 estimate after each of "
+                        f"the first {n} DDIM+NLC timesteps; values are for timestep {n} unless named otherwise"}
 
 
 class EdmWorkload:
@@ -171,8 +211,8 @@ class EdmWorkload:
                     tmpl[k] = torch.ones_like(tmpl[k]) / 4.0
             eps.load_state_dict(fill_state_dict(tmpl, seed=0))
             sig.load_state_dict(fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES))
-            eps.to(device).set_compute_dtype(dtype)
-            sig.to(device).set_compute_dtype(dtype)
+            set_precision(eps.to(device), dtype)
+            set_precision(sig.to(device), dtype)
             self.exp = EDMImageExperiment(eps, None, batch_size=self.batch, data_shape=(3, 32, 32), seed=0, device=device,
                                           num_timesteps=self.steps)
             self.exp.set_model(eps, sig, learn_epsvar=False)
@@ -245,8 +285,8 @@ class CelebaWorkload:
             eps, sig, _ = script_util.create_simple_sigma_eps_model(config)
             eps.load_state_dict(fill_state_dict(eps.state_dict(), seed=0))
             sig.load_state_dict(fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES))
-            eps.to(device).set_compute_dtype(dtype)
-            sig.to(device).set_compute_dtype(dtype)
+            set_precision(eps.to(device), dtype)
+            set_precision(sig.to(device), dtype)
             s = get_sampler("ddim", 1000, self.timesteps, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
             s.to(device)
             self.exp = ImageExperiment(eps, s, batch_size=self.batch, data_shape=(3, 256, 256), seed=5, device=device)
@@ -356,7 +396,9 @@ def main():
     ap.add_argument("--config", default="adm256", choices=sorted(WORKLOADS), help="adm256 = the headline metric (BASELINE.json configs[1])")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = the workload's default)")
     ap.add_argument("--timesteps", type=int, default=0, help="sampler timesteps (0 = the workload's default; ADM-256: 50 = the headline metric)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=sorted(PRECISIONS),
+                    help="bf16 (BASELINE.json configs[1]) | f16 (the reference's own use_fp16 mode) | f32 (exact f32 MFMA) | "
+                         "f32x3 (f32 storage, split-f16 three-pass matrix math: the 1e-3-parity path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay each network evaluation from a captured hipGraph")
@@ -386,8 +428,9 @@ def main():
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    wl = WORKLOADS[args.config](args, device, dtype)
+    prec = PRECISIONS[args.dtype]
+    dtype = prec[0]
+    wl = WORKLOADS[args.config](args, device, prec)
     if args.graph and wl.exp is not None:
         wl.exp.use_graphs = True
     n_total = (args.warmup + args.steps) * world
@@ -437,6 +480,10 @@ def main():
             line["roofline"] = roofline_leg(wl, xs[0], dtype, args)
         if not args.dry_run and not args.no_cpu_baseline and not args.tiny and world == 1:
             line["cpu_baseline"] = wl.cpu_baseline()
+            if hasattr(wl, "parity"):
+                par = wl.parity(args.dtype)
+                if par:
+                    line["parity"] = par
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
@@ -463,7 +510,7 @@ def roofline_leg(wl, x, dtype, args):
     sel = [(e0.elapsed_time(e1), f, shp) for e0, e1, f, d, shp in prof if d == dtype]
     tot_ms, tot_fl, n = sum(m for m, _, _ in sel), sum(f for _, f, _ in sel), len(sel)
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
-    peak = PEAK_BF16_DENSE_TFLOPS if dtype == torch.bfloat16 else 157.3
+    peak = PEAKS[args.dtype]
     out = {"bound": "mfma",
            "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3, >= 64 tiles) + conv_fast_kernel<{args.dtype},9|1> + conv_igemm_kernel",
            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
@@ -472,7 +519,7 @@ def roofline_leg(wl, x, dtype, args):
     # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
     # tagged with the hash of the kernel sources they were taken on
     tpath = ROOT / "profiles" / "r02_pmc_traffic.json"
-    if wl.name == "adm256" and wl.res == 256 and dtype == torch.bfloat16 and tpath.exists():
+    if wl.name == "adm256" and wl.res == 256 and args.dtype == "bf16" and tpath.exists():
         tj = json.loads(tpath.read_text())
         out["traffic"] = tj.get("conv2d_bytes_per_launch")
         out["traffic_source"] = {"file": "profiles/r02_pmc_traffic.json", "csrc_sha16": tj.get("csrc_sha16"),

@@ -15,8 +15,9 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NLC_HIP_LIB", _HERE / "libnlc_hip.so"))     # override: kernel A/B experiments only
 BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
 
-ABI_VERSION = 3                 # NLC_ABI_VERSION of include/nlc_hip.h
-NLC_F32, NLC_BF16 = 0, 1
+ABI_VERSION = 4                 # NLC_ABI_VERSION of include/nlc_hip.h
+NLC_F32, NLC_BF16, NLC_F16 = 0, 1, 2
+MATH_NATIVE, MATH_F16X3 = 0, 1      # nlc_conv_desc.math / nlc_pack_conv_weights_ex
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 SCHED_VARIANTS = {
@@ -59,6 +60,8 @@ class ConvDesc(C.Structure):
         ("gn_act", C.c_int32),
         ("tuning", C.c_int32),
         ("res_upsample2x", C.c_int32),
+        ("math", C.c_int32),
+        ("debug", C.c_int32),
     ]
 
 
@@ -96,6 +99,8 @@ SIGNATURES = {
     "nlc_last_error": (C.c_char_p, []),
     "nlc_conv_pack_dims": (C.c_int, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nlc_pack_conv_weights": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "nlc_pack_conv_weights_ex": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "nlc_has_experiments": (C.c_int, []),
     "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
@@ -137,12 +142,13 @@ SIGNATURES = {
 _lib = None
 
 
-def build(force: bool = False) -> Path:
-    """Compile the HIP sources for gfx950 (works without a GPU)."""
+def build(force: bool = False, experiments: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 (works without a GPU).  ``experiments``: also csrc/experiments/ (conv_wide,
+    conv_tall - never reached by the production dispatch, not part of the shipped library)."""
     if force:
         for o in (_HERE / "csrc" / "obj").glob("*.o"):
             o.unlink()
-    subprocess.run(["bash", str(BUILD_SCRIPT)], check=True)
+    subprocess.run(["bash", str(BUILD_SCRIPT)] + (["--experiments"] if experiments else []), check=True)
     return LIB_PATH
 
 

@@ -14,6 +14,7 @@
 //       f32 : ds_read_b32, with the same k permutation (k = 16kk + 4*(lane>>4) + j) on P and V.
 // All LDS images are row-major with the 16-byte chunk index XOR-swizzled by row bits.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -44,20 +45,7 @@ template <int RB> __device__ __forceinline__ int swz_chunk(int row, int c) {
 }
 template <int RB> __device__ __forceinline__ int lds_addr(int row, int c) { return row * RB + (swz_chunk<RB>(row, c) << 4); }
 
-template <typename T> struct AttnMma;
-template <> struct AttnMma<bf16_raw> {
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-    }
-};
-template <> struct AttnMma<float> {
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using AttnMma = Mfma16<T>;
 
 template <typename T, int D> struct AttnCfg {
     static constexpr int ES = (int)sizeof(T);
@@ -258,7 +246,6 @@ constexpr int F_TILE = FKV * 128;                      // one K or V tile: 64 ro
 constexpr int F_STAGE = F_SUB * F_TILE;
 constexpr int F_LDS = 4 * F_STAGE;                     // K0 K1 V0 V1 = 32 KiB
 
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ int fk_swz(int row) { return (row >> 1) & 7; }                              // ds_read_b128 of K rows
 __device__ __forceinline__ int fv_swz(int row) { return ((row & 3) << 1) | ((row >> 2) & 1); }          // ds_read_b64_tr_b16 of V
@@ -275,8 +262,8 @@ __device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_base)
                  : "memory");
 }
 
-__global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const bf16_raw* __restrict__ qkv, bf16_raw* __restrict__ out,
-                                                                    int Tn, int H) {
+template <typename T>
+__global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -294,22 +281,22 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const bf16_r
     const int pair = lin / nqb, qblk = lin - pair * nqb;
     const int b = pair / H, hd = pair - b * H, q0 = qblk * FQ_ROWS + wave * 32;
     const int64_t tok = (int64_t)3 * H * 64;            // elements between consecutive tokens
-    const bf16_raw* qb = qkv + (int64_t)b * Tn * tok + (int64_t)hd * 64;
-    const bf16_raw* kb = qb + (int64_t)H * 64;
-    const bf16_raw* vb = qb + (int64_t)2 * H * 64;
+    const T* qb = qkv + (int64_t)b * Tn * tok + (int64_t)hd * 64;
+    const T* kb = qb + (int64_t)H * 64;
+    const T* vb = qb + (int64_t)2 * H * 64;
 
     // Q^T fragments (B operand): lane (q, h) holds Q[q0 + q][16 s + 8 h + j], j = 0..7
-    bf16x8_t qf[4];
+    uint4 qf[4];
     {
-        const bf16_raw* qp = qb + (int64_t)(q0 + q) * tok + h * 8;
+        const T* qp = qb + (int64_t)(q0 + q) * tok + h * 8;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qp + s * 16));
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16);
     }
 
     // this wave's DMA piece of every tile: rows 8 wave .. 8 wave + 7; lane -> (row, 16-byte slot), source chunk = slot ^ swizzle(row)
     const int drow = wave * 8 + (lane >> 3), dslot = lane & 7;
-    const bf16_raw* ksrc = kb + (int64_t)drow * tok + ((dslot ^ fk_swz(drow)) << 3);
-    const bf16_raw* vsrc = vb + (int64_t)drow * tok + ((dslot ^ fv_swz(drow)) << 3);
+    const T* ksrc = kb + (int64_t)drow * tok + ((dslot ^ fk_swz(drow)) << 3);
+    const T* vsrc = vb + (int64_t)drow * tok + ((dslot ^ fv_swz(drow)) << 3);
     const unsigned dma_off = (unsigned)wave * 1024u;
     auto issue = [&](int tile, int stage) {               // `tile` counts stages of F_SUB x 64 keys
 #pragma unroll
@@ -364,10 +351,10 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const bf16_r
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const bf16x8_t ka = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Kt + koff[s]));
-            const bf16x8_t kc = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Kt + koff[s] + 4096));
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, qf[s], s1, 0, 0, 0);
+            const uint4 ka = *reinterpret_cast<const uint4*>(Kt + koff[s]);
+            const uint4 kc = *reinterpret_cast<const uint4*>(Kt + koff[s] + 4096);
+            s0 = Mfma16<T>::run32(ka, qf[s], s0);
+            s1 = Mfma16<T>::run32(kc, qf[s], s1);
         }
         // ---- online softmax, lane-local except one half exchange for the maximum
         // Row maximum of the RAW scores with v_max3_f32 from inline asm: fmaxf() on an MFMA output makes hipcc insert a
@@ -399,9 +386,18 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const bf16_r
         // ---- O^T += V^T P^T : P^T k-steps come straight from the score registers
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t pf;
+            uint4 pf;
+            if constexpr (std::is_same<T, bf16_raw>::value) {
+                bf16x8_t pb;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)((ks < 2 ? s0 : s1)[(ks & 1) * 8 + j]);
+                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)((ks < 2 ? s0 : s1)[(ks & 1) * 8 + j]);
+                pf = __builtin_bit_cast(uint4, pb);
+            } else {
+                f16x8_t ph;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ph[j] = (f16_raw)((ks < 2 ? s0 : s1)[(ks & 1) * 8 + j]);
+                pf = __builtin_bit_cast(uint4, ph);
+            }
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vt + vo[ks][db][0]));
@@ -411,8 +407,8 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const bf16_r
                 va.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
                 va.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
                 va.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, va), pf, o0, 0, 0, 0);
-                else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, va), pf, o1, 0, 0, 0);
+                if (db == 0) o0 = Mfma16<T>::run32(va, pf, o0);
+                else o1 = Mfma16<T>::run32(va, pf, o1);
             }
         }
       }
@@ -425,25 +421,25 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const bf16_r
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     const float inv = 1.0f / l;
-    bf16_raw* op = out + ((int64_t)b * Tn + q0 + q) * ((int64_t)H * 64) + (int64_t)hd * 64 + 4 * h;
+    T* op = out + ((int64_t)b * Tn + q0 + q) * ((int64_t)H * 64) + (int64_t)hd * 64 + 4 * h;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x16_t& o = db ? o1 : o0;
-            uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(o[4 * g] * inv) | ((unsigned)f32_to_bf16(o[4 * g + 1] * inv) << 16);
-            pk.y = (unsigned)f32_to_bf16(o[4 * g + 2] * inv) | ((unsigned)f32_to_bf16(o[4 * g + 3] * inv) << 16);
-            *reinterpret_cast<uint2*>(op + db * 32 + 8 * g) = pk;
+            const float ov[8] = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv, 0.f, 0.f, 0.f, 0.f};
+            const uint4 pk = f32_to_chunk<T>(ov);
+            *reinterpret_cast<uint2*>(op + db * 32 + 8 * g) = make_uint2(pk.x, pk.y);
         }
 }
 
+template <typename T>
 int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
     });
-    hipLaunchKernelGGL(attn_d64_kernel, dim3((Tn / FQ_ROWS) * H * B), dim3(FQ_WAVES * 64), F_LDS, st, (const bf16_raw*)qkv, (bf16_raw*)out, Tn, H);
+    hipLaunchKernelGGL(attn_d64_kernel<T>, dim3((Tn / FQ_ROWS) * H * B), dim3(FQ_WAVES * 64), F_LDS, st, (const T*)qkv, (T*)out, Tn, H);
     NLC_CHECK_LAUNCH("nlc_attention(d64)");
     return NLC_OK;
 }
@@ -480,10 +476,12 @@ int dispatch(const void* qkv, void* out, int B, int Tn, int H, int D, hipStream_
 extern "C" int nlc_attention(const void* qkv, void* out, int B, int T, int H, int D, int dtype, void* stream) {
     NLC_REQUIRE(qkv && out, "nlc_attention: null pointer");
     NLC_REQUIRE(B > 0 && T > 0 && H > 0 && D > 0, "nlc_attention: bad dims");
-    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_attention: bad dtype %d", dtype);
+    NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_attention: bad dtype %d", dtype);
     NLC_REQUIRE(H <= 65535 && B <= 65535 && (int64_t)B * H * (T / 64 + 1) < (1ll << 31), "nlc_attention: grid too large");
     // the ADM-256 shapes (64 channels per head, T = 1024 / 256): register-resident kernel above
-    if (dtype == NLC_BF16 && D == 64 && T % FQ_ROWS == 0) return launch_d64(qkv, out, B, T, H, (hipStream_t)stream);
+    if (nlc_is16(dtype) && D == 64 && T % FQ_ROWS == 0)
+        return dtype == NLC_BF16 ? launch_d64<bf16_raw>(qkv, out, B, T, H, (hipStream_t)stream) : launch_d64<f16_raw>(qkv, out, B, T, H, (hipStream_t)stream);
     if (dtype == NLC_BF16) return dispatch<bf16_raw>(qkv, out, B, T, H, D, (hipStream_t)stream);
+    if (dtype == NLC_F16) return dispatch<f16_raw>(qkv, out, B, T, H, D, (hipStream_t)stream);
     return dispatch<float>(qkv, out, B, T, H, D, (hipStream_t)stream);
 }

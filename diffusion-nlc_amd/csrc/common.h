@@ -10,6 +10,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef unsigned short bf16_raw;   // storage type for bf16 in memory
+typedef _Float16 f16_raw;          // storage type for IEEE half (NLC_F16): a distinct type, so every kernel template has both 16-bit forms
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define NLC_WAVE 64
 
@@ -55,6 +58,21 @@ template <> struct ElemTraits<bf16_raw> {
     __device__ static float load(const bf16_raw* p) { return bf16_to_f32(*p); }
     __device__ static void store(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
 };
+template <> struct ElemTraits<f16_raw> {
+    static constexpr int kPerChunk = 8;
+    static constexpr int kDtype = NLC_F16;
+    __device__ static float load(const f16_raw* p) { return (float)*p; }
+    __device__ static void store(f16_raw* p, float v) { *p = (f16_raw)v; }      // round-to-nearest-even (v_cvt_f16_f32)
+};
+
+static inline bool nlc_is16(int dtype) { return dtype == NLC_BF16 || dtype == NLC_F16; }
+static inline bool nlc_dtype_ok(int dtype) { return dtype == NLC_F32 || nlc_is16(dtype); }
+// run `...` with T16 = the 16-bit storage type of `dtype` (NLC_BF16 or NLC_F16)
+#define NLC_SWITCH_16(dtype, ...)                                       \
+    do {                                                                \
+        if ((dtype) == NLC_BF16) { using T16 = bf16_raw; __VA_ARGS__; } \
+        else { using T16 = f16_raw; __VA_ARGS__; }                      \
+    } while (0)
 
 // unpack a 16-byte chunk to floats / pack floats into a chunk
 template <typename T> __device__ __forceinline__ void chunk_to_f32(const uint4& c, float* f);
@@ -67,6 +85,11 @@ template <> __device__ __forceinline__ void chunk_to_f32<bf16_raw>(const uint4& 
     f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
     f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
     f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void chunk_to_f32<f16_raw>(const uint4& c, float* f) {
+    const f16x8_t h = __builtin_bit_cast(f16x8_t, c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = (float)h[k];
 }
 template <typename T> __device__ __forceinline__ uint4 f32_to_chunk(const float* f);
 template <> __device__ __forceinline__ uint4 f32_to_chunk<float>(const float* f) {
@@ -82,7 +105,46 @@ template <> __device__ __forceinline__ uint4 f32_to_chunk<bf16_raw>(const float*
     return c;
 }
 
-// bf16 paths: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of expf + IEEE division (~25 instructions per element)
+template <> __device__ __forceinline__ uint4 f32_to_chunk<f16_raw>(const float* f) {
+    f16x8_t h;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = (f16_raw)f[k];
+    return __builtin_bit_cast(uint4, h);
+}
+
+// ---- matrix cores: one 16-byte A fragment x one 16-byte B fragment into a 16x16 f32 tile.  16-bit types: ONE
+//      v_mfma_f32_16x16x32_{bf16,f16} (K = 32; the two run at the same rate on gfx950); f32: four exact
+//      v_mfma_f32_16x16x4_f32 with the same k permutation on both operands.  KBE = elements per 128-byte k-block.
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_raw> {
+    static constexpr int KBE = 64;
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+    __device__ static __forceinline__ f32x16_t run32(const uint4& a, const uint4& b, const f32x16_t& acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<f16_raw> {
+    static constexpr int KBE = 64;
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+    __device__ static __forceinline__ f32x16_t run32(const uint4& a, const uint4& b, const f32x16_t& acc) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<float> {
+    static constexpr int KBE = 32;
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+};
+
+// 16-bit paths: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of expf + IEEE division (~25 instructions per element)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) {

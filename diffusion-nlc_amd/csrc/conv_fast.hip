@@ -24,22 +24,7 @@ namespace {
 
 __device__ uint4 g_zero_page[8];      // 128 zero bytes: source of every out-of-image / out-of-channel chunk (and of a missing bias)
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_raw> {
-    static constexpr int KBE = KB_BYTES / 2;
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static constexpr int KBE = KB_BYTES / 4;
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using Mma = Mfma16<T>;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * KB_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -76,7 +61,10 @@ template <int N> __device__ __forceinline__ void dma_wait_n() { asm volatile("s_
 // STAGES = 2 (the only instantiation shipped): two workgroups per CU hide each other's DMA latency.  STAGES = 3 / 4 - one workgroup
 // per CU with the DMA of 2 / 3 k-steps in flight behind a counted wait - were measured on every shape of tools/conv_bench.py and
 // are slower everywhere, by 10-45 % (profiles/r02_summary.md): eight resident waves matter more than the deeper pipeline.
-template <typename T, int TAPS, int STAGES>
+// X3 (T = float, NLC_MATH_F16X3): f32 tensors, split-f16 matrix math (conv_halo.hip has the scheme).  The weights arrive packed as
+// (hi, lo) halves, so the two weight reads of a k-step ARE the two operand halves; the activation tile is staged once per tap here
+// and read by two waves only, so its fragments are split in registers (conv_params.h: f16x3_split4), 64 VALU per 48 MFMAs.
+template <typename T, int TAPS, int STAGES, bool X3 = false>
 __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = ElemTraits<T>::kPerChunk;
@@ -176,6 +164,32 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE_BYTES;
         const char* Bs = As + BM * KB_BYTES;
+        if constexpr (X3 && std::is_same<T, float>::value) {
+            // chunk fq holds channels 4 fq .. 4 fq + 3 of the 32-channel block, chunk 4 + fq channels 16 + 4 fq ..: together the eight
+            // k-values of one lane; the packed weights hold exactly those eight as hi halves in chunk fq, lo halves in chunk 4 + fq
+            uint4 wh[4], wl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wh[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, fq));
+                wl[j] = *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, 4 + fq));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (TAPS == 1 && i >= nlive) break;
+                const uint4 x0 = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, fq));
+                const uint4 x1 = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, 4 + fq));
+                uint2 h0, l0, h1, l1;
+                f16x3_split4(x0, h0, l0);
+                f16x3_split4(x1, h1, l1);
+                const uint4 ah = make_uint4(h0.x, h0.y, h1.x, h1.y), al = make_uint4(l0.x, l0.y, l1.x, l1.y);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mfma_f16(wh[j], ah, acc[i][j]);
+                    mfma_f16(wl[j], ah, acc[i][j]);
+                    mfma_f16(wh[j], al, acc[i][j]);
+                }
+            }
+        } else
         if (TAPS != 1 || nlive == 4) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -256,8 +270,11 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     //      [split][tile][wave][accumulator register 0..63][lane] (a wave-instruction moves 256 contiguous bytes); the workgroup that
     //      ARRIVES LAST at the tile (one self-resetting counter per tile) reads all of the tile's partials back in split order - a
     //      fixed summation order whoever is last - and runs the normal epilogue below.  The partials cross workgroups on different
-    //      XCDs (one L2 each) through relaxed AGENT-scope atomic accesses ordered by the counter; no release fence (it writes
-    //      back the XCD's whole dirty L2) and no separate reduce launch (conv_halo.hip has the same scheme).
+    //      XCDs (one L2 each) as sc1 (write-through) stores, drained, barrier, one lane's agent-scope atomic add; no release fence
+    //      (it writes back the XCD's whole dirty L2) and no separate reduce launch.  conv_halo.hip spells out the ordering argument.
+    //      Unlike that kernel this one runs TWO workgroups per CU, which is outside the geometry the sc1-loads-instead-of-acquire
+    //      hand-off is measured for, so the last arriver ALSO issues the agent-scope acquire (invalidates this CU's L1; ~2 us on a
+    //      25-50 us launch) before its loads.  tuning bit 10 adds the release on the producer side as well (stress test).
     if (p.ksplit > 1) {
         __shared__ int s_last;
         const int ks = p.ksplit;
@@ -276,10 +293,15 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's partial stores have been acknowledged ...
         __syncthreads();                                             // ... and every lane's, before the arrival is counted
         if (tid == 0) {
+            if (p.tuning & 1024) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             int* cnt = reinterpret_cast<int*>(p.partial) + bid;
             const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = old == ks - 1;
-            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-resetting
+            if (last) {
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-resetting
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             s_last = last;
         }
         __syncthreads();
@@ -427,14 +449,11 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                     *reinterpret_cast<uint4*>(op + c * PER) = pk;
                     if constexpr (sizeof(T) == 2) {
                         if (p.stats) {
-                            const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+                            float sv[8];
+                            chunk_to_f32<T>(pk, sv);
                             if (pix_stats) { gsum[c] = 0.f; gsq[c] = 0.f; }
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float lo = __uint_as_float(wds[q] << 16), hi = __uint_as_float(wds[q] & 0xffff0000u);
-                                gsum[c] += lo; gsum[c] += hi;
-                                gsq[c] = fmaf(lo, lo, gsq[c]); gsq[c] = fmaf(hi, hi, gsq[c]);
-                            }
+                            for (int q = 0; q < 8; ++q) { gsum[c] += sv[q]; gsq[c] = fmaf(sv[q], sv[q], gsq[c]); }
                         }
                     }
                 }
@@ -476,14 +495,14 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     }
 }
 
-template <typename T, int TAPS, int STAGES>
+template <typename T, int TAPS, int STAGES, bool X3 = false>
 int launch_fast(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fast_kernel<T, TAPS, STAGES, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   STAGES * STAGE_BYTES);
     });
-    hipLaunchKernelGGL((conv_fast_kernel<T, TAPS, STAGES>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), STAGES * STAGE_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_fast_kernel<T, TAPS, STAGES, X3>), dim3(p.MT * p.NT, p.ksplit), dim3(NTHREADS), STAGES * STAGE_BYTES, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(fast): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
@@ -506,10 +525,10 @@ static bool fast_shape(const KParams& p) {
 // 2 per CU and a long K; at least 2 channel blocks (18 / 2 k-steps) per split, at most 8 splits, aiming at >= 2
 // workgroups per CU (the 8x8 / 16x16 levels of ADM-256 at B = 16 have 64 / 256 tiles for 144-288 k-steps).
 int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
-    if ((p.Cout & 3) || !fast_shape(p)) return 1;
+    if ((p.Cout & 3) || !fast_shape(p) || (p.tuning & 2048)) return 1;       // bit 11: no split-K anywhere (A/B, stress test)
     const bool k3 = p.KH == 3;
     const int tiles = p.MT * p.NT;
-    const int ncb = p.Cin_pad / (dtype == NLC_BF16 ? Mma<bf16_raw>::KBE : Mma<float>::KBE);
+    const int ncb = p.Cin_pad / (nlc_is16(dtype) ? Mma<bf16_raw>::KBE : Mma<float>::KBE);
     if (tiles >= 512) return 1;
     int s = cdiv(512, tiles);
     const int min_cb = k3 ? 2 : 8;                   // >= 18 (3x3) / 8 (1x1) k-steps per split
@@ -521,7 +540,7 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
 // GroupNorm statistics ride along on the fast path when the N-tiles are whole and the output is bf16 NHWC: from the conv
 // epilogue if every 128-pixel tile lies inside one image, per pixel from the last-arriving workgroup when K is split
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
-    if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0 || !fast_shape(p)) return 0;
+    if (!nlc_is16(dtype) || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0 || !fast_shape(p)) return 0;
     const int HWo = p.Hout * p.Wout;
     if (nlc_conv_fast_ksplit(p, dtype) > 1) return HWo;          // split-K: the last-arriving workgroup emits one partial per pixel
     if (HWo % BM) return 0;
@@ -538,5 +557,7 @@ int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!fast_shape(p)) return NLC_EUNSUPPORTED;
     const bool k3 = p.KH == 3;
     if (dtype == NLC_BF16) return k3 ? launch_fast<bf16_raw, 9, 2>(p, stream) : launch_fast<bf16_raw, 1, 2>(p, stream);
+    if (dtype == NLC_F16) return k3 ? launch_fast<f16_raw, 9, 2>(p, stream) : launch_fast<f16_raw, 1, 2>(p, stream);
+    if (p.math == NLC_MATH_F16X3) return k3 ? launch_fast<float, 9, 2, true>(p, stream) : launch_fast<float, 1, 2, true>(p, stream);
     return k3 ? launch_fast<float, 9, 2>(p, stream) : launch_fast<float, 1, 2>(p, stream);
 }

@@ -42,22 +42,7 @@ constexpr int SCRATCH = 8 * 8 * KB_BYTES;       // landing zone of the padding D
 constexpr int COEF_STAGE = 1024;                // GroupNorm prologue: (a, b) of 128 input channels = one DMA piece, per halo stage
 constexpr int HALO_LDS = 2 * A_STAGE + NBST * B_STAGE + SCRATCH + 2 * COEF_STAGE;   // 159,744 B
 
-template <typename T> struct MmaH;
-template <> struct MmaH<bf16_raw> {
-    static constexpr int KBE = KB_BYTES / 2;
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-    }
-};
-template <> struct MmaH<float> {
-    static constexpr int KBE = KB_BYTES / 4;
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using MmaH = Mfma16<T>;
 
 __device__ __forceinline__ int hoff(int row, int chunk) { return row * KB_BYTES + ((chunk ^ (row & 7)) << 4); }
 
@@ -89,36 +74,18 @@ template <int N> __device__ __forceinline__ void dma_wait_h() { asm volatile("s_
 
 struct TileH { int tb, y0, x0, n0, cb0, cb1, ks, tix; };     // cb0 / cb1 / ks / tix: channel-block range, split index, tile index (SPLIT only)
 
-// ---- diagnostic build only (-DHALO_STAMP): s_memtime stamps around the phases of ONE k-step (tile 1, cb 1, tap 4) of
-//      workgroup 0, per wave; read back with nlc_debug_halo_stamps.  No stamp executes in the normal build.
-#ifdef HALO_STAMP
-#ifndef HALO_STAMP_TAP
-#define HALO_STAMP_TAP 4
-#endif
-__device__ unsigned long long g_halo_clock[4];     // {s_memtime, s_memrealtime} at loop start / end of workgroup 0, wave 0
-__device__ unsigned long long g_halo_stamps[8][8];
-__device__ unsigned long long g_halo_epi[8][6];    // inside the epilogue of tile 1: start, cadd loads issued, pixel loop done, stats done, acc re-initialised
-__device__ unsigned long long g_halo_steps[8][12];  // per wave: s_memtime at the start of each of the 9 taps of (tile 1, cb 1) + at the end of tap 8
-__device__ unsigned long long g_halo_cb[8][12];     // per wave: s_memtime at the start of every channel block of tile 1 (up to 10) + around its epilogue
-__device__ unsigned long long g_halo_tile[8][4];   // per wave: s_memtime before / after the epilogues of tiles 1 and 2 of workgroup 0
-#define STAMP(i) do { if (stamp_on && tap == HALO_STAMP_TAP) { __builtin_amdgcn_sched_barrier(0); st[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define STAMP_FLUSH() do { if (stamp_on && tap == HALO_STAMP_TAP && lane == 0) { for (int q_ = 0; q_ < 8; ++q_) g_halo_stamps[wave][q_] = st[q_]; } } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#define STAMP_FLUSH() do {} while (0)
-#endif
-#ifdef HALO_STAMP
-#define ESTAMP(i) do { if (blockIdx.x == 0 && lane == 0 && estamp_on) { __builtin_amdgcn_sched_barrier(0); g_halo_epi[wave][i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#else
-#define ESTAMP(i) do {} while (0)
-#endif
-
 // SPLIT: split-K for launches with fewer tiles than CUs (the 16x16 level): a list entry is (tile, channel-block range); every
 // workgroup writes its accumulators as raw f32 partial sums [split][M][Cout], and the workgroup that ARRIVES LAST at a tile (one
 // atomic counter per tile, self-resetting) reads all of the tile's partials back in split order - a fixed summation order whoever
 // is last - adds bias / embedding and runs the normal epilogue.  No reduce pass, statistics in the usual four-per-patch form.
 // A separate instantiation: the plain kernel keeps its code.
-template <typename T, bool GN, bool SPLIT = false>
+// X3 (T = float only, NLC_MATH_F16X3): the k-loop of the 16-bit kernel on f32 tensors.  A 128-byte k-block is 32 f32 channels; every
+// landed halo row is rewritten IN PLACE in LDS, once per element, by the wave that DMA'd it (the GroupNorm prologue's slot in the
+// schedule): 16-byte chunk c = 0..3 of a row then holds the f16 `hi` halves of channels 4c..4c+3 and 16+4c..16+4c+3, chunk 4+c the
+// `lo` halves of the same eight channels (conv_params.h: f16x3_split4; the weights arrive packed that way).  The two fragment reads
+// of a k-step that used to fetch the two k-halves now fetch a lane's eight hi and its eight lo values, and a k-step is
+// hi*hi, hi*lo, lo*hi = 48 v_mfma_f32_16x16x32_f16 per wave instead of 64 exact-f32 MFMAs at 1/8 the rate each.
+template <typename T, bool GN, bool SPLIT = false, bool X3 = false>
 __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = ElemTraits<T>::kPerChunk;
@@ -171,6 +138,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // (read + write of the whole activation) disappears.  Wave 1 additionally fetches the 64 (a, b) pairs of each channel
     // block (one 1-KiB piece = 128 channels, the second half is the next block's) into a two-stage LDS table.
     constexpr bool has_gn = GN && sizeof(T) == 2;    // a separate instantiation: the plain kernel keeps its register allocation
+    constexpr bool has_x3 = X3 && std::is_same<T, float>::value;
+    constexpr bool has_xf = has_gn || has_x3;        // landed halo rows are transformed in LDS by the wave that fetched them
+    static_assert(!(has_gn && has_x3), "GroupNorm prologue and split-f16 math are separate instantiations");
     const bool coef_wave = has_gn && wave == 1;      // wave-uniform
     const int ncb = p.Cin_pad / KBE;
     const int nk = ncb * 9;
@@ -231,26 +201,43 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // coefficients, computes and writes back.  Out-of-image rows stay zero: the convolution pads the NORMALISED input.
     auto xptr = [&](int astage, int j) { return smem + astage * A_STAGE + (wave * 8 + j * 64) * KB_BYTES + lane * 16; };
     auto xload = [&](int astage, int j) -> uint4 {
-        if constexpr (has_gn) return *reinterpret_cast<const uint4*>(xptr(astage, j));
+        if constexpr (has_xf) return *reinterpret_cast<const uint4*>(xptr(astage, j));
         else return uint4{0, 0, 0, 0};
     };
     auto xfinish = [&](int astage, int j, const uint4& d) {
         if constexpr (has_gn) {
             if ((hvalid >> j) & 1u) {
                 const float* cf = reinterpret_cast<const float*>(smemCoef + astage * COEF_STAGE) + hchunk * 16;
-                const unsigned w[4] = {d.x, d.y, d.z, d.w};
-                unsigned o[4];
+                float v[8];
+                chunk_to_f32<T>(d, v);
                 const bool silu = p.gn_act == NLC_ACT_SILU;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 ab = *reinterpret_cast<const float4*>(cf + q * 4);       // a0 b0 a1 b1
-                    float y0 = fmaf(__uint_as_float(w[q] << 16), ab.x, ab.y);
-                    float y1 = fmaf(__uint_as_float(w[q] & 0xffff0000u), ab.z, ab.w);
+                    float y0 = fmaf(v[2 * q], ab.x, ab.y);
+                    float y1 = fmaf(v[2 * q + 1], ab.z, ab.w);
                     if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); }
-                    o[q] = (unsigned)f32_to_bf16(y0) | ((unsigned)f32_to_bf16(y1) << 16);
+                    v[2 * q] = y0; v[2 * q + 1] = y1;
                 }
-                *reinterpret_cast<uint4*>(xptr(astage, j)) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4*>(xptr(astage, j)) = f32_to_chunk<T>(v);
             }
+        }
+        if constexpr (has_x3) {
+            // this lane's 16 bytes = channels 4c..4c+3 of one halo pixel, c = hchunk; the lane that holds chunk c ^ 4 of the same
+            // pixel is lane ^ 4 (slot = chunk ^ (row & 7)).  Chunk c < 4 keeps both lanes' hi halves, chunk c >= 4 both lanes' lo
+            // halves, each in channel order: one 8-byte exchange across the pair, VALU only (DPP row shifts by 4 under bank masks).
+            uint2 hi, lo;
+            f16x3_split4(d, hi, lo);
+            const bool keeps_hi = (hchunk & 4) == 0;
+            const uint2 send = keeps_hi ? lo : hi;
+            auto xor4 = [](unsigned x) {
+                int r = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);       // row_shl:4 -> lanes 0-3, 8-11 of a row read lane + 4
+                r = __builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xf, 0xa, false);           // row_shr:4 -> lanes 4-7, 12-15 read lane - 4
+                return (unsigned)r;
+            };
+            const uint2 recv = make_uint2(xor4(send.x), xor4(send.y));
+            const uint4 o = keeps_hi ? make_uint4(hi.x, hi.y, recv.x, recv.y) : make_uint4(recv.x, recv.y, lo.x, lo.y);
+            *reinterpret_cast<uint4*>(xptr(astage, j)) = o;
         }
     };
     auto xform = [&](int astage, int j) { xfinish(astage, j, xload(astage, j)); };
@@ -295,6 +282,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 
     // fragment sets (register double buffer)
     uint4 fa0[4], fb0[4], fa1[4], fb1[4];
+    uint4 fa2[has_x3 ? 4 : 1], fb2[has_x3 ? 4 : 1];     // X3: the next k-step's hi fragments (this step's stay live through all three products)
     auto load_frags = [&](uint4 (&fa)[4], uint4 (&fb)[4], int astage, int bstage, auto tap_c, auto kk_c) {
         constexpr int tap = decltype(tap_c)::value, kk = decltype(kk_c)::value;
         constexpr int r = tap / 3, s = tap % 3;
@@ -313,7 +301,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) MmaH<T>::run(fb[j], fa[i], acc[i][j]);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (has_x3) mfma_f16(fb[j], fa[i], acc[i][j]);
+                else MmaH<T>::run(fb[j], fa[i], acc[i][j]);
+            }
     };
 
     // ---- epilogue straight from registers: lane (fr, fq) of wave (wm, wn) holds, for patch row wm*4 + i and
@@ -377,10 +368,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cadd[j * 4], cadd[j * 4 + 1], cadd[j * 4 + 2], cadd[j * 4 + 3]};
     };
     auto epilogue = [&](const TileH& t, const TileH& nx) {
-#ifdef HALO_STAMP
-        const bool estamp_on = (tl - wi) / gx == 1;
-#endif
-        ESTAMP(0);
         float cnext[16];
         if constexpr (SPLIT) {
 #pragma unroll
@@ -388,15 +375,33 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         } else {
             load_cadd(nx, cnext);                    // in flight while this tile is stored
         }
-        ESTAMP(1);
         const int n = t.n0 + wn * 64 + fq * 16;
         float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};        // this lane's two 8-channel chunks over its 4 pixels
         bool done = false;
         bool parked = false;                         // SPLIT: this workgroup was not the last to arrive at its tile - no output from it
         if constexpr (SPLIT) {                       // dispatch: bf16, Cout % 128 == 0
-            // The partial sums cross workgroups that may sit on different XCDs (one L2 each): they are written and read with relaxed
-            // AGENT-scope atomic accesses (write-through / cache-bypassing), ordered by the arrival counter.  No release fence: on
-            // this chip an agent-scope release writes back the XCD's whole dirty L2 (measured: +80 us per launch).
+            // The partial sums cross workgroups that may sit on different XCDs.  Memory-ordering argument (gfx950; MI355X_MICROARCH.md,
+            // "Workgroup dispatch, XCD placement & inter-workgroup visibility"): a CU's vector L1 is never refreshed by other CUs'
+            // stores and the eight per-XCD L2s are not coherent with each other, so a hand-off needs every byte to (a) leave the
+            // producer's L2 and (b) be read past the consumer's L1.  Here
+            //   * every partial is stored with a relaxed AGENT-scope atomic store = `global_store_dword ... sc1`: write-through, the line
+            //     is not kept in the producing XCD's L2 (sc1 / atomic stores DROP it), so the bytes are at the memory side once the
+            //     store is acknowledged;
+            //   * every storing wave drains its stores (`s_waitcnt vmcnt(0)` counts acknowledgements), then the workgroup barrier, then
+            //     ONE lane's agent-scope atomic add on the tile's counter (atomics execute at the memory side): the add cannot overtake
+            //     any store of the workgroup;
+            //   * the workgroup whose add returns ksplit - 1 is last; its other waves start loading only behind a workgroup barrier
+            //     that the adding wave joins after its add has returned;
+            //   * every load of the partials is a relaxed agent-scope atomic load = `global_load_dword ... sc1` to registers (never
+            //     `flat_`): sc1 loads bypass the L1 and are served from L2, which cannot hold a stale copy because no plain access
+            //     ever touches these lines (written sc1, read sc1; the buffer is reused launch after launch in this one role).
+            // This is row 1 of the guide's table of hand-offs measured with sc1 loads in place of the acquire (one lane per storing
+            // workgroup signals with an agent-scope atomic add, last arriver told by the returned value, hipMalloc memory, 4-byte
+            // stores and loads, ONE workgroup per CU - which this kernel is).  It is measured behaviour of this chip, not a
+            // guarantee of the HIP memory model, hence tuning bit 10: the formally ordered variant (agent-scope release before the
+            // add, agent-scope acquire in the last arriver before its loads), which the stress test compares bit for bit
+            // (tests/test_ops_gpu.py::test_split_k_stress).  The release is what costs: it writes back the XCD's whole dirty L2
+            // (+80 us per launch measured), so it is not the default.
             __shared__ int s_last;
             // layout [split][tile][wave][accumulator register 0..63][lane]: a wave-instruction writes / reads 256 contiguous bytes (in the
             // [M][Cout] layout every lane of a dword access touched a cache line of its own: +130 us per launch), and the last
@@ -416,10 +421,13 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this lane's partial stores have been acknowledged ...
             __syncthreads();                         // ... and every lane's, before the workgroup's arrival is counted
             if (tid == 0) {
+                const bool fenced = (p.tuning & 1024) != 0;
+                if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 int* cnt = reinterpret_cast<int*>(p.partial) + t.tix;
                 const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = old == ksp - 1;
                 if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // self-resetting
+                if (last && fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                 s_last = last;
             }
             __syncthreads();
@@ -489,10 +497,8 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     }
                     T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
                     const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
-#ifndef HALO_NO_STORE                                          /* timing diagnostics only (tools/halo_variant.sh) */
                     *reinterpret_cast<uint4*>(op) = pk0;
                     *reinterpret_cast<uint4*>(op + 8) = pk1;
-#endif
                     if (has_stats) {     // of the STORED (bf16-rounded) values - what the GroupNorm that follows reads
                         float sv[16];
                         chunk_to_f32<T>(pk0, sv); chunk_to_f32<T>(pk1, sv + 8);
@@ -550,18 +556,13 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
                             const uint4 pk = f32_to_chunk<T>(v + c * PER);
-#ifndef HALO_NO_STORE                                      /* timing diagnostics only (tools/halo_stamps.sh) */
                             *reinterpret_cast<uint4*>(op + c * PER) = pk;
-#endif
                             if constexpr (sizeof(T) == 2) {
                                 if (p.stats) {           // GroupNorm statistics of what was just stored (the rounded values)
-                                    const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+                                    float sv[8];
+                                    chunk_to_f32<T>(pk, sv);
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) {
-                                        const float lo = __uint_as_float(wds[q] << 16), hi = __uint_as_float(wds[q] & 0xffff0000u);
-                                        gsum[c] += lo; gsum[c] += hi;
-                                        gsq[c] = fmaf(lo, lo, gsq[c]); gsq[c] = fmaf(hi, hi, gsq[c]);
-                                    }
+                                    for (int q = 0; q < 8; ++q) { gsum[c] += sv[q]; gsq[c] = fmaf(sv[q], sv[q], gsq[c]); }
                                 }
                             }
                         }
@@ -577,7 +578,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 }
             }
         }
-        ESTAMP(2);
         if constexpr (sizeof(T) == 2) {
             if (p.stats && n + 16 <= p.Cout && !parked) {
                 // reduce over the 16 pixel lanes (fr) of this quarter-wave in a fixed order, then one 16-byte store per
@@ -590,9 +590,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 }
             }
         }
-        ESTAMP(3);
         init_acc(cnext);
-        ESTAMP(4);
     };
 
     // ---- prologue (first tile only): halo of block 0, weights of steps 0..2
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     issue_B(cur.n0, t_cb0(cur), min(2, t_nk(cur) - 1), 2);
     dma_wait_h<NB>();                                // halo 0 + weights 0,1 landed (weights 2 may fly)
     __syncthreads();
-    if (has_gn) {                                    // first halo of the launch: normalise all six own instructions at once
+    if (has_xf) {                                    // first halo of the launch: transform all six own instructions at once
 #pragma unroll
         for (int j = 0; j < NA; ++j) xform(0, j);
         __syncthreads();
@@ -630,9 +628,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // (Tried and measured slower on this kernel, 1.18 vs 1.12 ms on 256->256 @256^2: running SIMD partner waves in
     //  complementary orders by giving waves 0-3 / 4-7 their barrier at different points of one instruction stream.)
     constexpr int wdist = 3;                         // weight tiles run 3 k-steps ahead
-#ifdef HALO_STAMP
-    if (blockIdx.x == 0 && tid == 0) { g_halo_clock[0] = __builtin_amdgcn_s_memtime(); g_halo_clock[1] = __builtin_amdgcn_s_memrealtime(); }
-#endif
     int bcur = 0, hs = 0;                            // weight stage / halo stage of the current k-step (run across tiles)
     for (;;) {
         const bool has_next = tl + gx < chunk_len;
@@ -642,12 +637,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         for (int cb = t_cb0(cur); cb < c_end; ++cb) {
             const bool last_cb = cb + 1 == c_end;
             const bool more = !last_cb || has_next;  // a halo follows this one in the stream
-#ifdef HALO_STAMP
-            const bool stamp_on = blockIdx.x == 0 && tl == wi + gx && cb == 1;
-            if (blockIdx.x == 0 && tl == wi + gx && lane == 0 && cb < 10) { __builtin_amdgcn_sched_barrier(0); g_halo_cb[wave][cb] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-            unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            unsigned long long stp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
             auto step = [&](auto tap_c) {
                 constexpr int tap = decltype(tap_c)::value;
                 const int bnext = (bcur + 1) & 3;
@@ -674,15 +663,12 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                         }
                     }
                 };
-#ifdef HALO_STAMP
-                if (stamp_on) { __builtin_amdgcn_sched_barrier(0); stp[tap] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#endif
                 // GroupNorm prologue: halo instructions (2t, 2t+1) of the NEXT channel block were issued at tap t and retired by this
                 // wave's wait at tap t + 2 (the coefficient piece: tap 0 -> retired at tap 1, published by that step's barrier).
                 // They are normalised in place one per step at taps 3..7 (instruction j = tap - 3; the sixth, which only wave 0 has,
                 // also at tap 7): the data read is issued here, ahead of the first MFMA cluster, the arithmetic follows the DMA issue.
                 // The barriers of those steps publish the result before tap 8 prefetches the next block's first fragments.
-                constexpr bool xf_tap = has_gn && tap >= 3 && tap <= 7;
+                constexpr bool xf_tap = has_xf && tap >= 3 && tap <= 7;
                 const bool xf_on = xf_tap && more;
                 uint4 xd0 = uint4{0, 0, 0, 0}, xd1 = uint4{0, 0, 0, 0};
                 if constexpr (xf_tap) {
@@ -691,12 +677,48 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                         if constexpr (tap == 7) { if (wave == 0) xd1 = xload(hs ^ 1, 5); }
                     }
                 }
-                STAMP(0);
                 // Each half: 8 fragment reads for a LATER cluster + 16 MFMAs.  The sched_group_barrier pattern makes the
                 // backend interleave them as [1 ds_read, 2 MFMA] x 8 instead of "all reads, then all MFMAs": an MFMA holds
                 // the SIMD's issue port for 8 of its 16 cycles, so a read slipped into each gap costs ~nothing and a wave
                 // keeps the matrix pipe fed on its own (stamps: the read bursts used to cost 100-290 cycles per half with
                 // the pipe idle).
+                auto xf_mid = [&]() {
+                    if constexpr (xf_tap) {
+                        if (xf_on) {
+                            // hard scheduling fences: the block's LDS reads must not be drawn into the [1 ds_read, 2 MFMA] groups around
+                            // it (that interleave kept 60+ registers live and spilled INSIDE the k-loop; a spill reload is a vector-
+                            // memory load whose wait drains every DMA in flight)
+                            __builtin_amdgcn_sched_barrier(0);
+                            xfinish(hs ^ 1, tap - 3, xd0);
+                            if constexpr (tap == 7) { if (wave == 0) xfinish(hs ^ 1, 5, xd1); }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                };
+                if constexpr (has_x3) {
+                    // (fa0, fb0) = this step's hi fragments, loaded during the previous step.  First cluster: hi*hi under the reads of
+                    // the lo fragments; second cluster: hi*lo + lo*hi (32 MFMAs) under the reads of the NEXT step's hi fragments,
+                    // which go to a third register set because this step's are still operands.
+                    load_frags(fa1, fb1, hs, bcur, tap_c, K1{});
+                    mma16(fa0, fb0);
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    }
+                    issue_dma();
+                    xf_mid();
+                    load_frags(fa2, fb2, nast, bnext, std::integral_constant<int, ntap>{}, K0{});
+                    mma16(fa0, fb1);                              // hi(input) x lo(weights)
+                    mma16(fa1, fb0);                              // lo(input) x hi(weights)
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { fa0[q] = fa2[q]; fb0[q] = fb2[q]; }
+                } else {
                 load_frags(fa1, fb1, hs, bcur, tap_c, K1{});      // this step's second half
                 mma16(fa0, fb0);
 #pragma unroll
@@ -704,23 +726,11 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
-                STAMP(3);
                 // DMA issue (~90 cycles per instruction for the issuing wave) sits BETWEEN the two MFMA clusters: a step
                 // starts with matrix work that is already in registers, and the first-dispatched waves 0-3 (which run
                 // ahead of their SIMD partners by ~150 cycles after every barrier) issue while waves 4-7 still compute.
                 issue_dma();
-                if constexpr (xf_tap) {
-                    if (xf_on) {
-                        // hard scheduling fences: the block's LDS reads must not be drawn into the [1 ds_read, 2 MFMA] groups around
-                        // it (that interleave kept 60+ registers live and spilled INSIDE the k-loop; a spill reload is a vector-
-                        // memory load whose wait drains every DMA in flight)
-                        __builtin_amdgcn_sched_barrier(0);
-                        xfinish(hs ^ 1, tap - 3, xd0);
-                        if constexpr (tap == 7) { if (wave == 0) xfinish(hs ^ 1, 5, xd1); }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                STAMP(1);
+                xf_mid();
                 load_frags(fa0, fb0, nast, bnext, std::integral_constant<int, ntap>{}, K0{});   // next step's first half
                 mma16(fa1, fb1);
 #pragma unroll
@@ -728,7 +738,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
-                STAMP(5);
+                }
                 // retire weights kt+2; instructions younger than them may stay in flight:
                 // this step's weights kt+3 (NB) and the halo instructions issued at this step or the previous one
                 // (issue order per step: weights, then 2 halo instructions at taps 0-2)
@@ -738,53 +748,33 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 else if constexpr (tap == 3) { if (more) dma_wait_h<NB + 2>(); else dma_wait_h<NB>(); }
                 else if constexpr (tap == 1 || tap == 2) { if (more) dma_wait_h<NB + 4>(); else dma_wait_h<NB>(); }
                 else dma_wait_h<NB>();
-                STAMP(6);
                 __syncthreads();
-                STAMP(7);
-                STAMP_FLUSH();
                 bcur = bnext;
                 ++kt;
             };
             step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
             step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-#ifdef HALO_STAMP
-            if (stamp_on) {
-                __builtin_amdgcn_sched_barrier(0); stp[9] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
-                if (lane == 0) { for (int q_ = 0; q_ < 10; ++q_) g_halo_steps[wave][q_] = stp[q_]; }
-            }
-#endif
             hs ^= 1;
         }
-#ifdef HALO_STAMP
-        const int tix_ = (tl - wi) / gx;
-        if (blockIdx.x == 0 && lane == 0 && (tix_ == 1 || tix_ == 2)) g_halo_tile[wave][(tix_ - 1) * 2] = __builtin_amdgcn_s_memtime();
-#endif
         epilogue(cur, nxt);                          // registers -> global, asynchronous stores; no LDS, no barrier
-#ifdef HALO_STAMP
-        if (blockIdx.x == 0 && lane == 0 && (tix_ == 1 || tix_ == 2)) g_halo_tile[wave][(tix_ - 1) * 2 + 1] = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 0 && lane == 0 && tix_ == 1) { g_halo_cb[wave][10] = g_halo_tile[wave][0]; g_halo_cb[wave][11] = g_halo_tile[wave][1]; }
-#endif
         if (!has_next) break;
         cur = nxt;
         tl += gx;
     }
-#ifdef HALO_STAMP
-    if (blockIdx.x == 0 && tid == 0) { g_halo_clock[2] = __builtin_amdgcn_s_memtime(); g_halo_clock[3] = __builtin_amdgcn_s_memrealtime(); }
-#endif
     dma_wait_h<0>();          // the redundant tail fetches
 }
 
-template <typename T, bool GN, bool SPLIT = false>
+template <typename T, bool GN, bool SPLIT = false, bool X3 = false>
 int launch_halo(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
     const int slot = nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, GN, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, GN, SPLIT, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
     });
     const int ncu = once.ncu[slot];
     const int nblk = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT * (SPLIT ? p.ksplit : 1);
     const int grid = nblk < ncu ? nblk : ncu;        // one persistent workgroup per CU (154 KiB of LDS each)
-    hipLaunchKernelGGL((conv_halo_kernel<T, GN, SPLIT>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
+    hipLaunchKernelGGL((conv_halo_kernel<T, GN, SPLIT, X3>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(halo): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
@@ -792,17 +782,6 @@ int launch_halo(const KParams& p, hipStream_t stream) {
 
 }  // namespace
 
-#ifdef HALO_STAMP
-extern "C" int nlc_debug_halo_stamps(unsigned long long* out) {
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamps), sizeof(unsigned long long) * 64);
-    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(g_halo_clock), sizeof(unsigned long long) * 4);
-    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 68, HIP_SYMBOL(g_halo_tile), sizeof(unsigned long long) * 32);
-    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 100, HIP_SYMBOL(g_halo_epi), sizeof(unsigned long long) * 48);
-    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 148, HIP_SYMBOL(g_halo_steps), sizeof(unsigned long long) * 96);
-    if (rc == 0) rc = (int)hipMemcpyFromSymbol(out + 244, HIP_SYMBOL(g_halo_cb), sizeof(unsigned long long) * 96);
-    return rc;
-}
-#endif
 
 static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     // per-call policy (nlc_conv_desc.policy): no process-wide switch, so the dispatch a test forces and the dispatch a
@@ -813,7 +792,7 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1)) return false;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     if (p.Hout % PATCH || p.Wout % PATCH || p.Hout != HL || p.Wout != WL) return false;
-    const int kbe = dtype == NLC_BF16 ? MmaH<bf16_raw>::KBE : MmaH<float>::KBE;
+    const int kbe = nlc_is16(dtype) ? MmaH<bf16_raw>::KBE : MmaH<float>::KBE;
     if (p.C0 % kbe || p.C1 % kbe || p.Cin_pad / kbe > 128) return false;
     if ((int64_t)p.B * p.Hout * p.Wout >= (1ll << 31)) return false;
     return true;
@@ -825,7 +804,7 @@ static int halo_tiles(const KParams& p) { return p.B * (p.Hout / PATCH) * (p.Wou
 // split - the 16x16 level of ADM-256 at B = 16 (1024->1024: 128 tiles x 2, 1024->512: 64 tiles x 4).  bf16, whole N-tiles, no
 // GroupNorm prologue; the caller opts in by passing the workspace (nlc_conv2d_workspace_bytes).  tuning bit 7 disables it (A/B).
 int nlc_conv_halo_ksplit(const KParams& p, int dtype) {
-    if (dtype != NLC_BF16 || p.gn_coef || (p.Cout % BN) != 0 || (p.tuning & 128)) return 1;
+    if (!nlc_is16(dtype) || p.gn_coef || (p.Cout % BN) != 0 || (p.tuning & (128 | 2048))) return 1;       // bit 11: no split-K anywhere (A/B, stress test)
     if (!halo_eligible(p, dtype, nullptr)) return 1;
     const int tiles = halo_tiles(p), ncb = p.Cin_pad / MmaH<bf16_raw>::KBE;
     if (tiles >= 256) return 1;
@@ -854,7 +833,7 @@ int nlc_conv_halo_prologue_ok(const KParams& p, int dtype) {
 // GroupNorm statistics ride along when the halo kernel runs in bf16 with NHWC output and whole 128-channel N-tiles: four partials
 // per 16x16 patch (split-K launches too: from the epilogue of the workgroup that arrives last at the tile)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
-    if (dtype != NLC_BF16 || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
+    if (!nlc_is16(dtype) || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
     if (nlc_conv_halo_ksplit(p, dtype) <= 1 && !halo_plain_ok(p, dtype)) return 0;
     return (p.Hout / PATCH) * (p.Wout / PATCH) * 4;
 }
@@ -865,9 +844,12 @@ int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
 int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (p.ksplit > 1) {
         if (nlc_conv_halo_ksplit(p, dtype) != p.ksplit || !p.partial) return NLC_EUNSUPPORTED;
+        if (dtype == NLC_F16) return launch_halo<f16_raw, false, true>(p, stream);
         return launch_halo<bf16_raw, false, true>(p, stream);
     }
     if (!halo_plain_ok(p, dtype)) return NLC_EUNSUPPORTED;
     if (dtype == NLC_BF16) return p.gn_coef ? launch_halo<bf16_raw, true>(p, stream) : launch_halo<bf16_raw, false>(p, stream);
+    if (dtype == NLC_F16) return launch_halo<f16_raw, false>(p, stream);      // (GroupNorm prologue: bf16 instantiation only - it is off by default)
+    if (p.math == NLC_MATH_F16X3) return launch_halo<float, false, false, true>(p, stream);
     return launch_halo<float, false>(p, stream);
 }

@@ -25,29 +25,15 @@
 
 namespace {
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_raw> {
-    static constexpr int KBE = KB_BYTES / 2;   // 64 elements per k-block
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static constexpr int KBE = KB_BYTES / 4;   // 32 elements per k-block
-    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-    }
-};
+template <typename T> using Mma = Mfma16<T>;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * KB_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename T>
+// X3 (T = float, NLC_MATH_F16X3 weights): this generic kernel only has to UNDERSTAND the (hi, lo) weight packing - it rebuilds
+// w = hi + lo (the 22-bit operand the split-f16 kernels multiply with) and runs the exact f32 MFMAs on it.
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = ElemTraits<T>::kPerChunk;
@@ -154,6 +140,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE_BYTES;
         const char* Bs = As + BM * KB_BYTES;
+        if constexpr (X3 && std::is_same<T, float>::value) {
+            uint4 fa0[4], fa1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa0[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, fq));
+                fa1[i] = *reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 16 + fr, 4 + fq));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f16x8_t wh = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, fq)));
+                const f16x8_t wl = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, 4 + fq)));
+                float wv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wv[e] = (float)wh[e] + (float)wl[e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float av[8] = {__uint_as_float(fa0[i].x), __uint_as_float(fa0[i].y), __uint_as_float(fa0[i].z), __uint_as_float(fa0[i].w),
+                                         __uint_as_float(fa1[i].x), __uint_as_float(fa1[i].y), __uint_as_float(fa1[i].z), __uint_as_float(fa1[i].w)};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wv[e], acc[i][j], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             uint4 fa[4], fb[4];
@@ -212,14 +222,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p
     }
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 int launch(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, X3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     });
-    hipLaunchKernelGGL(conv_igemm_kernel<T>, dim3(p.MT * p.NT), dim3(NTHREADS), LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, X3>), dim3(p.MT * p.NT), dim3(NTHREADS), LDS_BYTES, stream, p);
     NLC_CHECK_LAUNCH("nlc_conv2d");
     return NLC_OK;
 }
@@ -227,39 +237,66 @@ int launch(const KParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult) {
-    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv_pack_dims: bad dtype %d", dtype);
+    NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_conv_pack_dims: bad dtype %d", dtype);
     if (cout_mult) *cout_mult = BN;
-    if (cin_mult) *cin_mult = dtype == NLC_BF16 ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
+    if (cin_mult) *cin_mult = nlc_is16(dtype) ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
     return NLC_OK;
 }
 
-static void geometry_only(const nlc_conv_desc* d, KParams& p) {
-    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Cout = d->Cout;
-    p.Cin_pad = d->Cin_pad; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.B = d->B;
+#ifndef NLC_EXPERIMENTS
+// the shipped library has no conv_wide / conv_tall (csrc/experiments/, `build.sh --experiments`): inert stand-ins
+int nlc_conv_wide_stats_partials(const KParams&, int) { return 0; }
+int nlc_conv_wide_dispatch(const KParams&, int, hipStream_t) { return NLC_EUNSUPPORTED; }
+int nlc_conv_tall_stats_partials(const KParams&, int) { return 0; }
+int nlc_conv_tall_dispatch(const KParams&, int, hipStream_t) { return NLC_EUNSUPPORTED; }
+int nlc_conv_tall_prologue_ok(const KParams&, int) { return 0; }
+extern "C" int nlc_has_experiments(void) { return 0; }
+#else
+extern "C" int nlc_has_experiments(void) { return 1; }
+#endif
+
+// ONE function fills the kernel parameter block from the descriptor, for the three host queries and for nlc_conv2d alike, so that
+// a query predicts the dispatch from exactly the state the launch sees (Cout_pad, residual, math mode, ... included).
+static void fill_params(const nlc_conv_desc* d, KParams& p) {
+    p.x0 = (const char*)d->x0; p.x1 = (const char*)d->x1;
     p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
-    p.ups = d->upsample2x ? 1 : 0; p.out_mode = d->out_mode; p.policy = d->policy; p.tuning = d->tuning;
-    p.act = d->act; p.bias = d->bias; p.emb = d->emb; p.emb_stride = d->emb_stride; p.gn_coef = d->gn_coef;    // kernel choice looks at these
+    p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
+    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.ups = d->upsample2x ? 1 : 0;
+    p.w = (const char*)d->w; p.Cin_pad = d->Cin_pad; p.Cout_pad = d->Cout_pad;
+    p.bias = d->bias; p.emb = d->emb; p.emb_stride = d->emb_stride;
+    p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act; p.res_ups = d->res_upsample2x ? 1 : 0;
+    p.out = (char*)d->out; p.out_mode = d->out_mode;
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
+    p.ksplit = 1; p.partial = nullptr;
+    p.stats = nullptr; p.stats_P = 0;
+    p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math;
+    p.policy = d->policy; p.tuning = d->tuning;
+}
+
+static bool desc_sane(const nlc_conv_desc* d, int dtype) {
+    return d && nlc_dtype_ok(dtype) && d->B > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0 && d->policy != NLC_CONV_GENERIC;
 }
 
 extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype) {
-    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
+    if (!desc_sane(d, dtype)) return 0;
     KParams p{};
-    geometry_only(d, p);
+    fill_params(d, p);
+    if (nlc_conv_narrow_ok(p, dtype)) return 0;
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
-    if (d->policy == NLC_CONV_GENERIC) return 0;
     int ks = 1;
     if (nlc_conv_tall_stats_partials(p, dtype) == 0 && nlc_conv_wide_stats_partials(p, dtype) == 0) ks = nlc_conv_halo_ksplit(p, dtype);
     if (ks > 1) return (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) + 4096;      // arrival counters in front of the halo kernel's partial sums
+    if (nlc_conv_halo_plain_ok(p, dtype)) return 0;
     return nlc_conv_fast_split_bytes(p, nlc_conv_fast_ksplit(p, dtype));
 }
 
 extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
-    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
-    if (d->policy == NLC_CONV_GENERIC) return 0;
+    if (!desc_sane(d, dtype)) return 0;
     KParams p{};
-    geometry_only(d, p);
+    fill_params(d, p);
+    if (nlc_conv_narrow_ok(p, dtype)) return 0;          // the <= 16-channel kernel emits none
     int P = nlc_conv_tall_stats_partials(p, dtype);
     if (P > 0) return P;
     P = nlc_conv_wide_stats_partials(p, dtype);
@@ -270,18 +307,35 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
 }
 
 extern "C" int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype) {
-    if (!d || !(dtype == NLC_F32 || dtype == NLC_BF16) || d->B <= 0 || d->Hout <= 0 || d->Wout <= 0 || d->Cout <= 0) return 0;
-    if (d->policy == NLC_CONV_GENERIC) return 0;
+    if (!desc_sane(d, dtype)) return 0;
     KParams p{};
-    geometry_only(d, p);
+    fill_params(d, p);
+    p.gn_coef = nullptr;                                 // "the gn_* fields themselves are not looked at"
+    if (nlc_conv_narrow_ok(p, dtype)) return 0;
     return nlc_conv_tall_prologue_ok(p, dtype) || nlc_conv_halo_prologue_ok(p, dtype);
+}
+
+// nlc_conv_desc.debug bit 0: the split-K arrival counters (first 4 KiB of the workspace) must be zero when a launch starts - every
+// launch leaves them zero, so a non-zero word means an aborted launch or a foreign writer poisoned the workspace, after which
+// tiles would reduce early or never.  Synchronises the stream: tests and triage only.
+static int check_counters(const KParams& p, hipStream_t stream) {
+    static thread_local int host[1024];
+    if (hipMemcpyAsync(host, p.partial, sizeof(host), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        nlc_set_error("nlc_conv2d: could not read back the workspace's arrival counters");
+        return NLC_ELAUNCH;
+    }
+    for (int i = 0; i < 1024; ++i)
+        NLC_REQUIRE(host[i] == 0, "nlc_conv2d: split-K arrival counter %d of the workspace is %d, not 0 (poisoned workspace: re-zero its first 4096 bytes)", i, host[i]);
+    return NLC_OK;
 }
 
 extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(d != nullptr, "nlc_conv2d: null descriptor");
-    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv2d: bad dtype %d", dtype);
-    const int per = dtype == NLC_BF16 ? 8 : 4;
-    const int kbe = dtype == NLC_BF16 ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
+    NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_conv2d: bad dtype %d", dtype);
+    NLC_REQUIRE(d->math == NLC_MATH_NATIVE || (d->math == NLC_MATH_F16X3 && dtype == NLC_F32), "nlc_conv2d: math %d needs dtype NLC_F32", d->math);
+    const int per = nlc_is16(dtype) ? 8 : 4;
+    const int kbe = nlc_is16(dtype) ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
     NLC_REQUIRE(d->x0 && d->w && d->out, "nlc_conv2d: null tensor pointer");
     NLC_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0,
                 "nlc_conv2d: non-positive dims");
@@ -305,30 +359,19 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(!(d->emb) || d->emb_stride >= d->Cout, "nlc_conv2d: emb_stride < Cout");
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     NLC_REQUIRE(M64 < (1ll << 31) - BM, "nlc_conv2d: too many output pixels");
+    NLC_REQUIRE(!d->res_upsample2x || (d->res && d->Hout % 2 == 0 && d->Wout % 2 == 0), "nlc_conv2d: res_upsample2x needs a residual and even Hout, Wout");
+    NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
+    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_TALL, "nlc_conv2d: bad policy %d", d->policy);
+    if (d->policy > NLC_CONV_GENERIC && !nlc_has_experiments()) {
+        nlc_set_error("nlc_conv2d: policy %d selects an experimental kernel; this library was built without --experiments", d->policy);
+        return NLC_EUNSUPPORTED;
+    }
 
     KParams p;
-    p.x0 = (const char*)d->x0; p.x1 = (const char*)d->x1;
-    p.C0 = d->C0; p.C1 = d->C1; p.Ctot = d->C0 + d->C1;
-    p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
-    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
-    p.ups = d->upsample2x ? 1 : 0;
-    p.w = (const char*)d->w; p.Cin_pad = d->Cin_pad; p.Cout_pad = d->Cout_pad;
-    p.bias = d->bias; p.emb = d->emb; p.emb_stride = d->emb_stride;
-    p.res = (const char*)d->res; p.out_scale = d->out_scale; p.act = d->act; p.res_ups = d->res_upsample2x ? 1 : 0;
-    NLC_REQUIRE(!d->res_upsample2x || (d->res && d->Hout % 2 == 0 && d->Wout % 2 == 0), "nlc_conv2d: res_upsample2x needs a residual and even Hout, Wout");
-    p.out = (char*)d->out; p.out_mode = d->out_mode;
-    p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
-    p.ksplit = 1; p.partial = nullptr;
-    p.stats = nullptr; p.stats_P = 0;
-    p.gn_coef = d->gn_coef; p.gn_act = d->gn_act;
-    NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
+    fill_params(d, p);
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  policy NLC_CONV_GENERIC forces the latter (A/B runs).
-    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_TALL, "nlc_conv2d: bad policy %d", d->policy);
-    p.policy = d->policy; p.tuning = d->tuning;
     const bool force_generic = d->policy == NLC_CONV_GENERIC;
-    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
-    (void)HL; (void)WL;
     if (!force_generic) {
         int Pfast = 0;
         if (d->stats_out) {
@@ -336,7 +379,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             const int Pwide = Ptall > 0 ? Ptall : nlc_conv_wide_stats_partials(p, dtype);
             const int Phalo = Pwide > 0 ? Pwide : nlc_conv_halo_stats_partials(p, dtype);
             Pfast = Phalo > 0 ? 0 : nlc_conv_fast_stats_partials(p, dtype);
-            const int P = Phalo > 0 ? Phalo : Pfast;
+            const int P = nlc_conv_narrow_ok(p, dtype) ? 0 : (Phalo > 0 ? Phalo : Pfast);
             NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
             NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / 8) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
             p.stats = (float*)d->stats_out; p.stats_P = P;
@@ -352,6 +395,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         const int hks = nlc_conv_halo_ksplit(p, dtype);
         if (hks > 1 && d->workspace && d->workspace_bytes >= (int64_t)hks * p.M * p.Cout * (int64_t)sizeof(float) + 4096) {
             p.ksplit = hks; p.partial = (float*)d->workspace;
+            if (d->debug & 1) { const int cr = check_counters(p, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
         } else {
             NLC_REQUIRE(hks <= 1 || !d->stats_out || nlc_conv_halo_plain_ok(p, dtype), "nlc_conv2d: stats_out on a split-K shape needs the workspace of nlc_conv2d_workspace_bytes");
         }
@@ -363,6 +407,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             const int ks = nlc_conv_fast_ksplit(p, dtype);
             if (ks > 1 && d->workspace_bytes >= nlc_conv_fast_split_bytes(p, ks)) {
                 p.ksplit = ks; p.partial = (float*)d->workspace;
+                if (d->debug & 1) { const int cr = check_counters(p, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
             }
         }
         // the statistics layout was sized for the kernel that nlc_conv2d_stats_partials predicted (split-K reduce: one
@@ -374,6 +419,9 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         p.ksplit = 1; p.partial = nullptr;
     }
     NLC_REQUIRE(!p.gn_coef, "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue");
+    NLC_REQUIRE(!p.stats, "nlc_conv2d: stats_out given but the generic kernel emits no statistics");
     if (dtype == NLC_BF16) return launch<bf16_raw>(p, (hipStream_t)stream);
+    if (dtype == NLC_F16) return launch<f16_raw>(p, (hipStream_t)stream);
+    if (p.math == NLC_MATH_F16X3) return launch<float, true>(p, (hipStream_t)stream);
     return launch<float>(p, (hipStream_t)stream);
 }

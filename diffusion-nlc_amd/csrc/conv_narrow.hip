@@ -1,4 +1,4 @@
-// 3x3 stride-1 pad-1 convolution with at most 16 output channels (bf16): the networks' last layer, GroupNorm -> SiLU -> conv to
+// 3x3 stride-1 pad-1 convolution with at most 16 output channels (bf16 / f16): the networks' last layer, GroupNorm -> SiLU -> conv to
 // 6 / 3 channels (src/unet_adm.py:613-617, src/unet_simple.py conv_out).  The 128-channel N-tile of conv_halo.hip did 21x the
 // matrix work for it and - one barrier, one counted wait and 2.7 DMA pieces per wave for every tap - was issue-bound at 0.76 us per
 // k-step (436 us per launch on 256 -> 6 @256^2, B = 16, for 537 MB of input).
@@ -44,6 +44,7 @@ __device__ __forceinline__ void nglds(const void* gptr, unsigned lds_base) {
 
 struct TileN { int tb, y0, x0; };
 
+template <typename T>
 __global__ __launch_bounds__(NTH, 1) void conv_narrow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ES = 2, PER = 8, KBE = 64;
@@ -144,8 +145,7 @@ __global__ __launch_bounds__(NTH, 1) void conv_narrow_kernel(const KParams p) {
                         const int k = (i + r) * HALO + s;                     // compile-time
                         // channels kh * 32 + fq * 8 .. of the 64-channel block = 16-byte chunk kh * 4 + fq: (fq ^ row) ^ (kh * 4) << 4
                         const uint4 af = *reinterpret_cast<const uint4*>(As + (aoffm[k & 7] ^ (kh * 64)) + k * KB_BYTES);
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, af),
-                                                                         acc[i], 0, 0, 0);
+                        Mfma16<T>::run(wf, af, acc[i]);
                     }
                 }
             }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NTH, 1) void conv_narrow_kernel(const KParams p) {
                 if (ch < p.Cout) {
                     const float v = acc[i][r] * p.out_scale;
                     if (p.out_mode == NLC_OUT_NHWC)
-                        reinterpret_cast<bf16_raw*>(p.out)[(((int64_t)cur.tb * p.Hout + y) * p.Wout + x) * p.Cout + ch] = f32_to_bf16(v);
+                        ElemTraits<T>::store(reinterpret_cast<T*>(p.out) + (((int64_t)cur.tb * p.Hout + y) * p.Wout + x) * p.Cout + ch, v);
                     else
                         reinterpret_cast<float*>(p.out)[((int64_t)cur.tb * p.Cout + ch) * HWo + (int64_t)y * p.Wout + x] = v;
                 }
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NTH, 1) void conv_narrow_kernel(const KParams p) {
 }
 
 bool narrow_eligible(const KParams& p, int dtype) {
-    if (dtype != NLC_BF16 || p.policy != NLC_CONV_AUTO || (p.tuning & 512)) return false;       // tuning bit 9: A/B switch
+    if (!nlc_is16(dtype) || p.policy != NLC_CONV_AUTO || (p.tuning & 512)) return false;       // tuning bit 9: A/B switch
     if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1) || p.ups) return false;
     if (p.Cout > 16 || p.Cout_pad < 16 || p.C1 != 0 || p.C0 % 64 || p.C0 / 64 > 128) return false;
     if (p.Hout % PATCH || p.Wout % PATCH || p.Hout != p.Hin || p.Wout != p.Win) return false;
@@ -193,12 +193,13 @@ int nlc_conv_narrow_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!narrow_eligible(p, dtype) || p.stats) return NLC_EUNSUPPORTED;
     static DeviceOnce once;
     const int slot = nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_narrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_narrow_kernel<bf16_raw>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_narrow_kernel<f16_raw>), hipFuncAttributeMaxDynamicSharedMemorySize, NARROW_LDS);
     });
     const int ncu = once.ncu[slot];
     const int ntile = p.B * (p.Hout / PATCH) * (p.Wout / PATCH);
     const int grid = ntile < ncu ? ntile : ncu;
-    hipLaunchKernelGGL(conv_narrow_kernel, dim3(grid), dim3(NTH), NARROW_LDS, stream, p);
+    NLC_SWITCH_16(dtype, hipLaunchKernelGGL(conv_narrow_kernel<T16>, dim3(grid), dim3(NTH), NARROW_LDS, stream, p));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(narrow): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;

@@ -29,7 +29,24 @@ struct KParams {
     int tuning;         // A/B switches (nlc_conv_desc.tuning)
     const float* gn_coef; int gn_act;   // conv_halo (bf16) only: input = act(a x + b) applied in LDS (nlc_conv_desc.gn_coef)
     int res_ups;        // res is [B][Hout/2][Wout/2][Cout]: output pixel (y, x) adds res pixel (y >> 1, x >> 1) (nlc_conv_desc.res_upsample2x)
+    int math;           // NLC_MATH_* (nlc_conv_desc.math): f32 tensors only; F16X3 = weights packed as (hi, lo) f16 halves
 };
+
+// ---- NLC_MATH_F16X3: an f32 operand as two f16 halves, x ~= hi + lo with hi = f16(x) (round to nearest), lo = f16(x - hi); the
+//      residual x - hi is exact in f32, so hi + lo carries 22 significand bits of x (lo falls into f16's subnormal range, absolute
+//      precision 2^-25, for |x| < 2^-2).  Four f32 values -> (two packed hi words, two packed lo words).
+__device__ __forceinline__ void f16x3_split4(const uint4& x, uint2& hi, uint2& lo) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const float f0 = __uint_as_float(x.x), f1 = __uint_as_float(x.y), f2 = __uint_as_float(x.z), f3 = __uint_as_float(x.w);
+    const h2 h01 = {(_Float16)f0, (_Float16)f1}, h23 = {(_Float16)f2, (_Float16)f3};
+    const h2 l01 = {(_Float16)(f0 - (float)h01[0]), (_Float16)(f1 - (float)h01[1])};
+    const h2 l23 = {(_Float16)(f2 - (float)h23[0]), (_Float16)(f3 - (float)h23[1])};
+    hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+}
+__device__ __forceinline__ void mfma_f16(const uint4& a, const uint4& b, f32x4_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
 
 // row (pixel index) of the residual tensor that output pixel (y, x) of image tb / output row m adds
 __device__ __forceinline__ int64_t res_row(const KParams& p, int tb, int y, int x) {
@@ -55,7 +72,7 @@ int nlc_conv_halo_plain_ok(const KParams& p, int dtype);          // the un-spli
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: partials per image the halo kernel would emit GroupNorm statistics with for this launch (0: it would not)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype);
-// conv_wide.hip: the 512-pixel-tile variant of the halo kernel (bf16, big launches); same conventions as the two below
+// experiments/conv_wide.hip (only in --experiments builds): the 512-pixel-tile variant of the halo kernel; same conventions as the two below
 int nlc_conv_wide_stats_partials(const KParams& p, int dtype);
 int nlc_conv_wide_dispatch(const KParams& p, int dtype, hipStream_t stream);
 int nlc_conv_tall_stats_partials(const KParams& p, int dtype);     // conv_tall.hip: 256-pixel x 256-channel tiles

@@ -175,9 +175,10 @@ __global__ __launch_bounds__(NT) void conv_first_kernel(const float* __restrict_
 //      GroupNorm statistics of the output ride along (per 8-channel chunk (sum, sumsq), one partial per workgroup).
 constexpr int F1_PIX = 64;
 constexpr int F1_LD = 80;          // LDS bytes per patch row: 64 B of k + 16 B pad (conflict-free 16-byte fragment reads)
+template <typename T>
 __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                             bf16_raw* __restrict__ out, int Cin, int H, int W, int Cout,
+                                                             T* __restrict__ out, int Cin, int H, int W, int Cout,
                                                              int KH, int KW, int tiles_per_blk, int blks_per_img,
                                                              float* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) char patch[2][F1_PIX * F1_LD];
@@ -188,14 +189,14 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
     const float sc = in_scale ? in_scale[b] : 1.0f;
     const int ph = KH / 2, pw = KW / 2;
     // this wave's weights: MFMA tile j row fr <-> channel wave*64 + (fr>>2)*16 + j*4 + (fr&3); k = fq*8 .. fq*8+7
-    bf16x8_t wf[4];
+    uint4 wf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ch = wave * 64 + (fr >> 2) * 16 + j * 4 + (fr & 3);
         float f[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const int kk = fq * 8 + k; f[k] = (ch < Cout && kk < K) ? w[(int64_t)ch * K + kk] : 0.f; }
-        wf[j] = __builtin_bit_cast(bf16x8_t, f32_to_chunk<bf16_raw>(f));
+        wf[j] = f32_to_chunk<T>(f);
     }
     const int n = wave * 64 + fq * 16;                       // this lane's 16 output channels
     float cb[16];
@@ -220,41 +221,38 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
                     const int iy = oy + r - ph, ix = ox + s_ - pw;
                     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((int64_t)b * Cin + c) * H + iy) * W + ix] * sc;
                 }
-                *reinterpret_cast<bf16_raw*>(pt + pp * F1_LD + k * 2) = f32_to_bf16(v);
+                ElemTraits<T>::store(reinterpret_cast<T*>(pt + pp * F1_LD + k * 2), v);
             }
         }
         __syncthreads();                                     // double-buffered patch: one barrier per tile
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(pt + (i * 16 + fr) * F1_LD + fq * 16);
+            const uint4 af = *reinterpret_cast<const uint4*>(pt + (i * 16 + fr) * F1_LD + fq * 16);
             float v[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4_t acc = f32x4_t{cb[j * 4], cb[j * 4 + 1], cb[j * 4 + 2], cb[j * 4 + 3]};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc, 0, 0, 0);
+                Mfma16<T>::run(wf[j], af, acc);
                 v[j * 4] = acc[0]; v[j * 4 + 1] = acc[1]; v[j * 4 + 2] = acc[2]; v[j * 4 + 3] = acc[3];
             }
             const int m = tile * F1_PIX + i * 16 + fr;
             if (m < HW && n < Cout) {
-                bf16_raw* op = out + ((int64_t)b * HW + m) * Cout + n;
+                T* op = out + ((int64_t)b * HW + m) * Cout + n;
                 if (n + 16 <= Cout && (Cout & 7) == 0) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        const uint4 pk = f32_to_chunk<bf16_raw>(v + c * 8);
+                        const uint4 pk = f32_to_chunk<T>(v + c * 8);
                         *reinterpret_cast<uint4*>(op + c * 8) = pk;
                         if (stats) {
-                            const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+                            float sv[8];
+                            chunk_to_f32<T>(pk, sv);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float lo = __uint_as_float(wds[q] << 16), hi = __uint_as_float(wds[q] & 0xffff0000u);
-                                gsum[c] += lo; gsum[c] += hi;
-                                gsq[c] = fmaf(lo, lo, gsq[c]); gsq[c] = fmaf(hi, hi, gsq[c]);
-                            }
+                            for (int q = 0; q < 8; ++q) { gsum[c] += sv[q]; gsq[c] = fmaf(sv[q], sv[q], gsq[c]); }
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) if (n + k < Cout) op[k] = f32_to_bf16(v[k]);
+                    for (int k = 0; k < 16; ++k) if (n + k < Cout) ElemTraits<T>::store(op + k, v[k]);
                 }
             }
         }
@@ -274,7 +272,7 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
 
 // workgroups per image of the MFMA first-layer kernel (also the number of statistics partials), 0 = not eligible
 static int conv_first_mfma_blocks(int Cin, int H, int W, int Cout, int KH, int KW, int dtype) {
-    if (dtype != NLC_BF16 || KH * KW * Cin > 32 || Cout > 256) return 0;
+    if (!nlc_is16(dtype) || KH * KW * Cin > 32 || Cout > 256) return 0;
     const int ntile = ((int64_t)H * W + F1_PIX - 1) / F1_PIX;
     int nb = ntile < 64 ? ntile : 64;
     return nb < 1 ? 1 : nb;
@@ -282,14 +280,16 @@ static int conv_first_mfma_blocks(int Cin, int H, int W, int Cout, int KH, int K
 
 }  // namespace
 
-#define DISPATCH_T(dtype, KERNEL, grid, block, st, ...)                                        \
-    do {                                                                                       \
-        if ((dtype) == NLC_BF16) hipLaunchKernelGGL(KERNEL<bf16_raw>, grid, block, 0, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL(KERNEL<float>, grid, block, 0, st, __VA_ARGS__);               \
+// launch KERNEL<T> for the storage type of `dtype`; X / OUT name the (void*) tensors that take the element type
+#define LAUNCH_T(dtype, KERNEL, grid, st, XEXPR, OEXPR, ...)                                                                              \
+    do {                                                                                                                                  \
+        if ((dtype) == NLC_BF16) hipLaunchKernelGGL(KERNEL<bf16_raw>, grid, dim3(NT), 0, st, (const bf16_raw*)(XEXPR), (bf16_raw*)(OEXPR), __VA_ARGS__); \
+        else if ((dtype) == NLC_F16) hipLaunchKernelGGL(KERNEL<f16_raw>, grid, dim3(NT), 0, st, (const f16_raw*)(XEXPR), (f16_raw*)(OEXPR), __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<float>, grid, dim3(NT), 0, st, (const float*)(XEXPR), (float*)(OEXPR), __VA_ARGS__);                \
     } while (0)
 
 static int check_nhwc(const char* name, const void* x, const void* out, int B, int H, int W, int C, int dtype) {
-    if (!(dtype == NLC_F32 || dtype == NLC_BF16)) { nlc_set_error("%s: bad dtype %d", name, dtype); return NLC_EINVAL; }
+    if (!nlc_dtype_ok(dtype)) { nlc_set_error("%s: bad dtype %d", name, dtype); return NLC_EINVAL; }
     if (!x || !out) { nlc_set_error("%s: null pointer", name); return NLC_EINVAL; }
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) { nlc_set_error("%s: bad dims", name); return NLC_EINVAL; }
     return NLC_OK;
@@ -297,33 +297,30 @@ static int check_nhwc(const char* name, const void* x, const void* out, int B, i
 
 extern "C" int nlc_avgpool2x2(const void* x, void* out, int B, int H, int W, int C, int dtype, void* stream) {
     int rc = check_nhwc("nlc_avgpool2x2", x, out, B, H, W, C, dtype); if (rc) return rc;
-    const int per = dtype == NLC_BF16 ? 8 : 4;
+    const int per = nlc_is16(dtype) ? 8 : 4;
     NLC_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % per == 0, "nlc_avgpool2x2: H,W must be even and C a multiple of %d", per);
     const int64_t work = (int64_t)B * (H / 2) * (W / 2) * (C / per);
-    if (dtype == NLC_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_raw>, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, (const bf16_raw*)x, (bf16_raw*)out, B, H, W, C);
-    else hipLaunchKernelGGL(avgpool_kernel<float>, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, H, W, C);
+    LAUNCH_T(dtype, avgpool_kernel, dim3(grid_for(work)), (hipStream_t)stream, x, out, B, H, W, C);
     NLC_CHECK_LAUNCH("nlc_avgpool2x2");
     return NLC_OK;
 }
 
 extern "C" int nlc_upsample2x(const void* x, void* out, int B, int H, int W, int C, int dtype, void* stream) {
     int rc = check_nhwc("nlc_upsample2x", x, out, B, H, W, C, dtype); if (rc) return rc;
-    const int per = dtype == NLC_BF16 ? 8 : 4;
+    const int per = nlc_is16(dtype) ? 8 : 4;
     NLC_REQUIRE(C % per == 0, "nlc_upsample2x: C must be a multiple of %d", per);
     const int64_t work = (int64_t)B * H * 2 * W * 2 * (C / per);
-    if (dtype == NLC_BF16) hipLaunchKernelGGL(upsample_kernel<bf16_raw>, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, (const bf16_raw*)x, (bf16_raw*)out, B, H, W, C);
-    else hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, H, W, C);
+    LAUNCH_T(dtype, upsample_kernel, dim3(grid_for(work)), (hipStream_t)stream, x, out, B, H, W, C);
     NLC_CHECK_LAUNCH("nlc_upsample2x");
     return NLC_OK;
 }
 
 extern "C" int nlc_pad_rb(const void* x, void* out, int B, int H, int W, int C, int dtype, void* stream) {
     int rc = check_nhwc("nlc_pad_rb", x, out, B, H, W, C, dtype); if (rc) return rc;
-    const int per = dtype == NLC_BF16 ? 8 : 4;
+    const int per = nlc_is16(dtype) ? 8 : 4;
     NLC_REQUIRE(C % per == 0, "nlc_pad_rb: C must be a multiple of %d", per);
     const int64_t work = (int64_t)B * (H + 1) * (W + 1) * (C / per);
-    if (dtype == NLC_BF16) hipLaunchKernelGGL(pad_rb_kernel<bf16_raw>, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, (const bf16_raw*)x, (bf16_raw*)out, B, H, W, C);
-    else hipLaunchKernelGGL(pad_rb_kernel<float>, dim3(grid_for(work)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, H, W, C);
+    LAUNCH_T(dtype, pad_rb_kernel, dim3(grid_for(work)), (hipStream_t)stream, x, out, B, H, W, C);
     NLC_CHECK_LAUNCH("nlc_pad_rb");
     return NLC_OK;
 }
@@ -334,6 +331,7 @@ extern "C" int nlc_nhwc_to_nchw_f32(const void* x, float* out, int B, int H, int
     dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
     NLC_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "nlc_nhwc_to_nchw_f32: grid too large");
     if (dtype == NLC_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_raw>, grid, dim3(NT), 0, (hipStream_t)stream, (const bf16_raw*)x, out, HW, C);
+    else if (dtype == NLC_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_raw>, grid, dim3(NT), 0, (hipStream_t)stream, (const f16_raw*)x, out, HW, C);
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, (const float*)x, out, HW, C);
     NLC_CHECK_LAUNCH("nlc_nhwc_to_nchw_f32");
     return NLC_OK;
@@ -345,6 +343,7 @@ extern "C" int nlc_nchw_f32_to_nhwc(const float* x, void* out, int B, int H, int
     dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
     NLC_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "nlc_nchw_f32_to_nhwc: grid too large");
     if (dtype == NLC_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_raw>, grid, dim3(NT), 0, (hipStream_t)stream, x, (bf16_raw*)out, HW, C);
+    else if (dtype == NLC_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_raw>, grid, dim3(NT), 0, (hipStream_t)stream, x, (f16_raw*)out, HW, C);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, x, (float*)out, HW, C);
     NLC_CHECK_LAUNCH("nlc_nchw_f32_to_nhwc");
     return NLC_OK;
@@ -369,7 +368,7 @@ extern "C" int nlc_conv_first_stats_partials(int Cin, int H, int W, int Cout, in
 extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const float* w, const float* bias, void* out_nhwc,
                               int B, int Cin, int H, int W, int Cout, int KH, int KW, int dtype,
                               void* stats_out, int64_t stats_bytes, void* stream) {
-    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_conv_first: bad dtype %d", dtype);
+    NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_conv_first: bad dtype %d", dtype);
     NLC_REQUIRE(x_nchw && w && out_nhwc, "nlc_conv_first: null pointer");
     NLC_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "nlc_conv_first: bad dims");
     NLC_REQUIRE(Cin >= 1 && Cin <= 4, "nlc_conv_first: Cin=%d must be in 1..4", Cin);
@@ -388,8 +387,8 @@ extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const 
             const int tpb = (ntile + nb - 1) / nb;
             const int nblk = (ntile + tpb - 1) / tpb;
             NLC_REQUIRE(!want_stats || nblk == nb, "nlc_conv_first: internal: partial count mismatch");
-            hipLaunchKernelGGL(conv_first_mfma_kernel, dim3(nblk, B), dim3(NT), 0, (hipStream_t)stream, x_nchw, in_scale, w, bias,
-                               (bf16_raw*)out_nhwc, Cin, H, W, Cout, KH, KW, tpb, nb, (float*)stats_out);
+            NLC_SWITCH_16(dtype, hipLaunchKernelGGL(conv_first_mfma_kernel<T16>, dim3(nblk, B), dim3(NT), 0, (hipStream_t)stream, x_nchw, in_scale, w,
+                                                    bias, (T16*)out_nhwc, Cin, H, W, Cout, KH, KW, tpb, nb, (float*)stats_out));
             NLC_CHECK_LAUNCH("nlc_conv_first");
             return NLC_OK;
         }
@@ -398,6 +397,7 @@ extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const 
     const int64_t nblk = (int64_t)B * H * tiles_x;
     NLC_REQUIRE(nblk < (1ll << 31), "nlc_conv_first: grid too large");
     if (dtype == NLC_BF16) hipLaunchKernelGGL(conv_first_kernel<bf16_raw>, dim3((unsigned)nblk), dim3(NT), 0, (hipStream_t)stream, x_nchw, in_scale, w, bias, (bf16_raw*)out_nhwc, B, Cin, H, W, Cout, KH, KW);
+    else if (dtype == NLC_F16) hipLaunchKernelGGL(conv_first_kernel<f16_raw>, dim3((unsigned)nblk), dim3(NT), 0, (hipStream_t)stream, x_nchw, in_scale, w, bias, (f16_raw*)out_nhwc, B, Cin, H, W, Cout, KH, KW);
     else hipLaunchKernelGGL(conv_first_kernel<float>, dim3((unsigned)nblk), dim3(NT), 0, (hipStream_t)stream, x_nchw, in_scale, w, bias, (float*)out_nhwc, B, Cin, H, W, Cout, KH, KW);
     NLC_CHECK_LAUNCH("nlc_conv_first");
     return NLC_OK;

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NT) void gn_apply_pool_kernel(const GNParams p, con
 }
 
 int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, int dtype) {
-    const int per = dtype == NLC_BF16 ? 8 : 4, es = dtype == NLC_BF16 ? 2 : 4;
+    const int per = nlc_is16(dtype) ? 8 : 4, es = nlc_is16(dtype) ? 2 : 4;
     p.x0 = (const char*)x0; p.x1 = (const char*)x1;
     p.C0 = C0; p.C1 = C1; p.C = C0 + C1; p.B = B; p.HW = HW; p.G = groups; p.gs = p.C / groups;
     p.nch = p.C / per;
@@ -527,6 +527,14 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
 }
 
 }  // namespace
+
+// run `...` with TG = the storage type of `dtype` (three instantiations of every GroupNorm kernel)
+#define GN_SWITCH(dtype, ...)                                            \
+    do {                                                                 \
+        if ((dtype) == NLC_BF16) { using TG = bf16_raw; __VA_ARGS__; }   \
+        else if ((dtype) == NLC_F16) { using TG = f16_raw; __VA_ARGS__; } \
+        else { using TG = float; __VA_ARGS__; }                          \
+    } while (0)
 
 // Pixels per apply workgroup: `unit` (= ps x unroll x 4 trips) for the big maps, capped so the grid stays <= GN_APPLY_MAXBLK
 // workgroups; halved down to `ps` (one chunk per thread) while the launch would have fewer than 512 workgroups - the 8x8 ... 32x32
@@ -549,8 +557,8 @@ extern "C" int64_t nlc_groupnorm_workspace_bytes(int B, int HW, int C, int group
 extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, float eps,
                              const float* gamma, const float* beta, const float* scale, const float* shift,
                              int ss_stride, int silu, void* out, void* workspace, int dtype, void* stream) {
-    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_groupnorm: bad dtype %d", dtype);
-    const int per = dtype == NLC_BF16 ? 8 : 4;
+    NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_groupnorm: bad dtype %d", dtype);
+    const int per = nlc_is16(dtype) ? 8 : 4;
     NLC_REQUIRE(x0 && out && workspace, "nlc_groupnorm: null pointer");
     NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm: bad dims");
     NLC_REQUIRE(C0 % per == 0 && C1 % per == 0, "nlc_groupnorm: C0=%d, C1=%d must be multiples of %d", C0, C1, per);
@@ -568,7 +576,7 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
     const size_t lds_apply = ((size_t)2 * p.C + 2 * p.G) * sizeof(float);
     NLC_REQUIRE(lds_stats <= 64 * 1024 && lds_apply <= 64 * 1024, "nlc_groupnorm: LDS budget exceeded (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    const int es = dtype == NLC_BF16 ? 2 : 4;
+    const int es = nlc_is16(dtype) ? 2 : 4;
     int64_t chunks = (int64_t)HW * p.nch;
     int nblk2 = cdiv(chunks, NT * 8);
     if (nblk2 < 1) nblk2 = 1;
@@ -582,21 +590,14 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
         const int nblk_a = cdiv(HW, ppb);
         const bool inline_fin = p.nblk <= 8;         // small maps: no finalize launch, the apply threads fold the partials
         if (inline_fin) stat = nullptr;
-        if (dtype == NLC_BF16) {
-            hipLaunchKernelGGL(gn_stats_fast_kernel<bf16_raw>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
+        GN_SWITCH(dtype,
+            hipLaunchKernelGGL(gn_stats_fast_kernel<TG>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
             if (!inline_fin) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
-            hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(nblk_a, B), dim3(NT), 0, st, p, stat, ppb);
-        } else {
-            hipLaunchKernelGGL(gn_stats_fast_kernel<float>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-            if (!inline_fin) hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
-            hipLaunchKernelGGL(gn_apply_fast_kernel<float>, dim3(nblk_a, B), dim3(NT), 0, st, p, stat, ppb);
-        }
-    } else if (dtype == NLC_BF16) {
-        hipLaunchKernelGGL(gn_stats_kernel<bf16_raw>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-        hipLaunchKernelGGL(gn_apply_kernel<bf16_raw>, dim3(nblk2, B), dim3(NT), lds_apply, st, p);
+            hipLaunchKernelGGL(gn_apply_fast_kernel<TG>, dim3(nblk_a, B), dim3(NT), 0, st, p, stat, ppb));
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk2, B), dim3(NT), lds_apply, st, p);
+        GN_SWITCH(dtype,
+            hipLaunchKernelGGL(gn_stats_kernel<TG>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
+            hipLaunchKernelGGL(gn_apply_kernel<TG>, dim3(nblk2, B), dim3(NT), lds_apply, st, p));
     }
     NLC_CHECK_LAUNCH("nlc_groupnorm");
     return NLC_OK;
@@ -606,7 +607,7 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
                                       const float* gamma, const float* beta, const float* scale, const float* shift,
                                       int ss_stride, int silu, void* out, void* workspace, int dtype,
                                       const float* stats0, int P0, const float* stats1, int P1, void* stream) {
-    NLC_REQUIRE(dtype == NLC_BF16, "nlc_groupnorm_prestats: bf16 only (the f32 path computes its statistics itself)");
+    NLC_REQUIRE(nlc_is16(dtype), "nlc_groupnorm_prestats: bf16 / f16 only (the f32 path computes its statistics itself)");
     NLC_REQUIRE(x0 && out && workspace && stats0 && P0 > 0, "nlc_groupnorm_prestats: null pointer");
     NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm_prestats: bad dims");
     NLC_REQUIRE((C1 == 0) == (x1 == nullptr) && (C1 == 0) == (stats1 == nullptr) && (C1 == 0 || P1 > 0),
@@ -632,7 +633,7 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
 #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
     p.coef = coef;
 #endif
-    hipLaunchKernelGGL(gn_apply_fast_kernel<bf16_raw>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb);
+    NLC_SWITCH_16(dtype, hipLaunchKernelGGL(gn_apply_fast_kernel<T16>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb));
     NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
     return NLC_OK;
 }
@@ -641,16 +642,16 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
                                      const float* beta, const float* scale, const float* shift, int ss_stride, int silu,
                                      void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0,
                                      void* stream) {
-    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_groupnorm_pool2x2: bad dtype %d", dtype);
-    const int per = dtype == NLC_BF16 ? 8 : 4;
+    NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_groupnorm_pool2x2: bad dtype %d", dtype);
+    const int per = nlc_is16(dtype) ? 8 : 4;
     NLC_REQUIRE(x && out_norm && out_x && workspace, "nlc_groupnorm_pool2x2: null pointer");
     NLC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && groups > 0 && H % 2 == 0 && W % 2 == 0, "nlc_groupnorm_pool2x2: bad dims (H, W even)");
     NLC_REQUIRE(C % per == 0 && C % groups == 0, "nlc_groupnorm_pool2x2: C=%d must be a multiple of %d and of groups=%d", C, per, groups);
     NLC_REQUIRE(C / per <= NT, "nlc_groupnorm_pool2x2: C=%d too large for the one-chunk-per-thread kernels", C);
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_pool2x2: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_pool2x2: ss_stride < C");
-    NLC_REQUIRE(!stats0 || (dtype == NLC_BF16 && P0 > 0 && (C / groups) % 8 == 0),
-                "nlc_groupnorm_pool2x2: ride-along statistics are bf16 only, group size a multiple of 8");
+    NLC_REQUIRE(!stats0 || (nlc_is16(dtype) && P0 > 0 && (C / groups) % 8 == 0),
+                "nlc_groupnorm_pool2x2: ride-along statistics are bf16 / f16 only, group size a multiple of 8");
     const int HW = H * W;
     GNParams p;
     fill_params(p, x, nullptr, C, 0, B, HW, groups, dtype);
@@ -668,17 +669,13 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
     } else {
         const size_t lds_stats = (size_t)p.ps * p.C * 3 * sizeof(float);
         NLC_REQUIRE(lds_stats <= 64 * 1024, "nlc_groupnorm_pool2x2: LDS budget exceeded (C=%d)", C);
-        if (dtype == NLC_BF16) hipLaunchKernelGGL(gn_stats_fast_kernel<bf16_raw>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
-        else hipLaunchKernelGGL(gn_stats_fast_kernel<float>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p);
+        GN_SWITCH(dtype, hipLaunchKernelGGL(gn_stats_fast_kernel<TG>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p));
         if (p.nblk <= 8) stat = nullptr;             // small maps: the apply threads fold the partials themselves
         else hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(NT), 0, st, p, stat);
     }
     const int OHW = HW / 4;
     const int oppb = apply_pix_per_block(OHW, B, p.ps, p.ps * 2 * 4);      // 4 unrolled trips of 2 x ps output pixels (= 8 x ps input pixels)
-    if (dtype == NLC_BF16)
-        hipLaunchKernelGGL(gn_apply_pool_kernel<bf16_raw>, dim3(cdiv(OHW, oppb), B), dim3(NT), 0, st, p, stat, W, oppb, (bf16_raw*)out_x);
-    else
-        hipLaunchKernelGGL(gn_apply_pool_kernel<float>, dim3(cdiv(OHW, oppb), B), dim3(NT), 0, st, p, stat, W, oppb, (float*)out_x);
+    GN_SWITCH(dtype, hipLaunchKernelGGL(gn_apply_pool_kernel<TG>, dim3(cdiv(OHW, oppb), B), dim3(NT), 0, st, p, stat, W, oppb, (TG*)out_x));
     NLC_CHECK_LAUNCH("nlc_groupnorm_pool2x2");
     return NLC_OK;
 }

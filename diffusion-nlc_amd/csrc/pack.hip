@@ -28,6 +28,34 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, 
     }
 }
 
+// NLC_MATH_F16X3 packing of an f32 weight tensor: one thread per f16 slot of the packed tensor (two slots per weight).  Within a
+// 32-channel k-block (64 slots = 8 chunks of 8): chunk c < 4 holds the hi halves of channels 4c..4c+3 and 16+4c..16+4c+3, chunk 4 + c
+// the lo halves of the same eight channels (include/nlc_hip.h: nlc_pack_conv_weights_ex; conv_halo.hip reads it).
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, int Cout_pad, int Cin_pad,
+                                                      const int32_t* __restrict__ row_perm, const double* __restrict__ row_scale,
+                                                      const int32_t* __restrict__ col_perm, f16_raw* __restrict__ packed) {
+    const int64_t n = (int64_t)Cout_pad * taps * Cin_pad * 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int slot = (int)(i & 63);
+        const int64_t blk = i >> 6;                          // (row, tap, 32-channel block)
+        const int ncb = Cin_pad / 32;
+        const int cb = (int)(blk % ncb);
+        const int64_t rt = blk / ncb;
+        const int tap = (int)(rt % taps);
+        const int r = (int)(rt / taps);
+        const int chunk = slot >> 3, e = slot & 7;
+        const int c = cb * 32 + (e < 4 ? 4 * (chunk & 3) + e : 16 + 4 * (chunk & 3) + (e - 4));
+        float v = 0.f;
+        if (r < Cout && c < Cin) {
+            const int sr = row_perm ? row_perm[r] : r, sc = col_perm ? col_perm[c] : c;
+            const double x = (double)w[((int64_t)sr * Cin + sc) * taps + tap];
+            v = (float)(row_scale ? x * row_scale[r] : x);
+        }
+        const f16_raw hi = (f16_raw)v;
+        packed[i] = chunk < 4 ? hi : (f16_raw)(v - (float)hi);
+    }
+}
+
 __global__ void pack_bias_kernel(const float* __restrict__ bias, int Cout, const int32_t* __restrict__ row_perm,
                                  const double* __restrict__ row_scale, const double* __restrict__ bias_add,
                                  float* __restrict__ out) {
@@ -44,8 +72,16 @@ __global__ void pack_bias_kernel(const float* __restrict__ bias, int Cout, const
 extern "C" int nlc_pack_conv_weights(const float* w, const float* bias, int Cout, int Cin, int KH, int KW,
                                      const int32_t* row_perm, const double* row_scale, const double* bias_add,
                                      const int32_t* col_perm, int dtype, void* packed, float* bias_out, void* stream) {
+    return nlc_pack_conv_weights_ex(w, bias, Cout, Cin, KH, KW, row_perm, row_scale, bias_add, col_perm, dtype, NLC_MATH_NATIVE, packed,
+                                    bias_out, stream);
+}
+
+extern "C" int nlc_pack_conv_weights_ex(const float* w, const float* bias, int Cout, int Cin, int KH, int KW,
+                                        const int32_t* row_perm, const double* row_scale, const double* bias_add,
+                                        const int32_t* col_perm, int dtype, int math, void* packed, float* bias_out, void* stream) {
     NLC_REQUIRE(w && packed, "nlc_pack_conv_weights: null pointer");
-    NLC_REQUIRE(dtype == NLC_F32 || dtype == NLC_BF16, "nlc_pack_conv_weights: bad dtype %d", dtype);
+    NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_pack_conv_weights: bad dtype %d", dtype);
+    NLC_REQUIRE(math == NLC_MATH_NATIVE || (math == NLC_MATH_F16X3 && dtype == NLC_F32), "nlc_pack_conv_weights: math %d needs dtype NLC_F32", math);
     NLC_REQUIRE(Cout > 0 && Cin > 0 && KH >= 1 && KW >= 1 && KH <= 7 && KW <= 7, "nlc_pack_conv_weights: bad dims");
     NLC_REQUIRE(bias_out || (!bias && !bias_add), "nlc_pack_conv_weights: bias / bias_add given without bias_out");
     int cm = 0, km = 0;
@@ -58,6 +94,12 @@ extern "C" int nlc_pack_conv_weights(const float* w, const float* bias, int Cout
     if (dtype == NLC_BF16)
         hipLaunchKernelGGL(pack_kernel<bf16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, Cout_pad, Cin_pad,
                            row_perm, row_scale, col_perm, (bf16_raw*)packed);
+    else if (dtype == NLC_F16)
+        hipLaunchKernelGGL(pack_kernel<f16_raw>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, Cout_pad, Cin_pad,
+                           row_perm, row_scale, col_perm, (f16_raw*)packed);
+    else if (math == NLC_MATH_F16X3)
+        hipLaunchKernelGGL(pack_x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, Cout_pad, Cin_pad,
+                           row_perm, row_scale, col_perm, (f16_raw*)packed);
     else
         hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, Cout_pad, Cin_pad,
                            row_perm, row_scale, col_perm, (float*)packed);

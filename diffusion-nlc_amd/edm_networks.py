@@ -186,7 +186,7 @@ class SongUNet(HipModule):
                 P.aux_conv = pack(sd, p, dtype, device)
             else:
                 P.dec.append((bool(kw.get("cat")), _UNetBlock(sd, p, dtype, device, bank, kw.get("attention", False), up=kw.get("up", False))))
-        bank.finalize(device, allow_split=dtype == torch.bfloat16)
+        bank.finalize(device, allow_split=ops.is16(dtype))
         P.bank = bank
         return P
 
@@ -264,7 +264,7 @@ class SigmaModel(HipModule):
         layout, _ = self._layout()
         P.blocks = [(pad, _UNetBlock(sd, blk, dtype, device, None, attn, pure=True), pack(sd, down + ".conv", dtype, device))
                     for pad, blk, attn, down in layout]
-        P.head = SigmaHead(sd, device, ACT_SILU, allow_split=dtype == torch.bfloat16)
+        P.head = SigmaHead(sd, device, ACT_SILU, allow_split=ops.is16(dtype))
         return P
 
     def run_nhwc(self, h):

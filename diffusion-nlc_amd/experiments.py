@@ -292,11 +292,13 @@ class ExperimentDiffusion:
     def denoise_loop(self, shape, gen=None, norm_init_noise=False, style="base", constrain_fn=None, norm_eps=False,
                      refine_prior_sigma=False, xT=None, return_log=True, chunk_size=2, sigma_pred_threshold=1000,
                      new_eta=None, constrain_loss=None, return_best=True, free_const_steps=-1, noise_list=None,
-                     return_on_device=False):
+                     return_on_device=False, max_steps=None):
         """src/experiments.py:329-397.  ``noise_list`` (optional) supplies the per-step N(0,1) draws that
         stochastic samplers consume; by default they come from the global CPU generator, one
         ``randn(shape)`` per step, in step order.  ``return_on_device`` keeps the returned sample in HBM (the
-        reference returns it on the CPU, :396; the sharded driver gathers it over RCCL first)."""
+        reference returns it on the CPU, :396; the sharded driver gathers it over RCCL first).  ``max_steps`` stops after
+        that many timesteps of the schedule (parity checks against a partial oracle trajectory); with ``return_log`` the
+        NLC-corrected per-sample sigma_t of every timestep is kept in ``self.sigma_trace`` (a list of CPU [B] tensors)."""
         S = self.scheduler
         S.reset_state()
         dev = self.device
@@ -325,7 +327,10 @@ class ExperimentDiffusion:
             flag_host = torch.zeros(2, dtype=torch.int32).pin_memory()
             flag_ev = [torch.cuda.Event(), torch.cuda.Event()]
             x0_before = x0
+        self.sigma_trace = []
         for ind, (t, t_prev) in enumerate(pairwise(ts_host.tolist())):
+            if max_steps is not None and ind >= max_steps:
+                break
             if ind == S.num_inference_steps - 1 and new_eta is not None:
                 S.eta = new_eta
             cur_style, cur_refine = style, bool(refine_prior_sigma)
@@ -347,6 +352,7 @@ class ExperimentDiffusion:
             else:
                 best_x0 = x0
             if return_log:
+                self.sigma_trace.append(st["sigma_t"].cpu())
                 z_list.append(ops.scale_rows(xt, torch.sqrt(1 / (st["sigma_prev"] ** 2 + 1))).cpu())   # logging only
                 eps_list.append(eps_used.cpu())
                 x0_prec_list.append(x0_hat.cpu())

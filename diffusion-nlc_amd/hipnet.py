@@ -6,11 +6,15 @@ A ``HipModule`` looks like the ``nn.Module`` it replaces to the reference's entr
 ``eval``, ``convert_to_fp16``) but owns no autograd state: parameters are plain f32 host tensors
 that are packed once per (device, compute dtype) into the layouts the kernels want.
 
-Compute dtype: ``torch.float32`` (exact f32 MFMA, the parity path) or ``torch.bfloat16``
-(bf16 operands / f32 accumulate, the throughput path).  The reference's ``convert_to_fp16``
-maps to bf16 here: like the reference's fp16 mode it touches convolution operands only -
-GroupNorm statistics, softmax, timestep-embedding MLPs and the sigma head stay f32
+Compute dtype: ``torch.float32`` (the parity path), ``torch.bfloat16`` or ``torch.float16`` (16-bit operands /
+f32 accumulate, the throughput paths; the two run at the same MFMA rate on gfx950).  The reference's
+``convert_to_fp16`` is ``torch.float16`` here as it is upstream, and like upstream it touches convolution /
+attention operands only - GroupNorm statistics, softmax, timestep-embedding MLPs and the sigma head stay f32
 (src/fp16_util.py:15-22, src/unet_adm.py:620-626,1060-1065).
+A float32 model additionally has a matrix mode (``set_matmul``): ``"native"`` = exact f32 MFMA (1/16 of the 16-bit
+rate), ``"f16x3"`` = every convolution operand split into two f16 halves, three 16-bit MFMA passes, f32 accumulate
+(include/nlc_hip.h NLC_MATH_F16X3: ~22 significand bits per operand, 3/16 of the 16-bit rate); storage and every
+non-convolution kernel stay exact f32 either way.
 """
 from __future__ import annotations
 
@@ -85,14 +89,16 @@ class HipModule:
     def _graph_call(self, fn, args, kwargs):
         self._require_gpu()
         items = list(args) + [kwargs[k] for k in sorted(kwargs)]
-        key = (fn.__name__, self.compute_dtype, ops.CONV_POLICY, len(args), tuple(sorted(kwargs)),
+        key = (fn.__name__, self.compute_dtype, self.matmul, ops.CONV_POLICY, ops.CONV_TUNING, ops.FUSE_GN_CONV, ops.FUSE_GN_POOL,
+               ops.FUSED_GN_STATS, len(args), tuple(sorted(kwargs)),
                tuple((tuple(a.shape), a.dtype) if torch.is_tensor(a) else a for a in items))
         cache = self.__dict__.setdefault("_graphs", {})
         ent = cache.get(key)
         with torch.cuda.device(self.device):
             if ent is None:
                 self.plan()
-                fn(self, *args, **kwargs)                        # eager once: every kernel's one-time launch setup happens here
+                fn(self, *args, **kwargs)                        # eager once: every kernel's one-time launch setup happens here, and
+                                                                 # the conv / GroupNorm workspaces reach their final size OUTSIDE the capture
                 static = [a.clone() if torch.is_tensor(a) else a for a in items]
                 s_args = static[:len(args)]
                 s_kwargs = dict(zip(sorted(kwargs), static[len(args):]))
@@ -117,6 +123,7 @@ class HipModule:
             self._sd[k] = torch.zeros(shape, dtype=dt)
         self.device = torch.device("cpu")
         self.compute_dtype = torch.float32
+        self.matmul = "native"
         self._plan = None
         self.training = False
 
@@ -181,19 +188,30 @@ class HipModule:
         return self.to(torch.device("cuda", torch.cuda.current_device() if index is None else index))
 
     def set_compute_dtype(self, dtype: torch.dtype):
-        if dtype == torch.float16:
-            dtype = torch.bfloat16
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise TypeError("compute dtype must be float32 or bfloat16")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise TypeError("compute dtype must be float32, bfloat16 or float16")
         if dtype != self.compute_dtype:
             self.compute_dtype = dtype
             self._plan = None                  # captured graphs are keyed by the compute dtype and hold their own weights' plan
             self.drop_graphs()
         return self
 
+    def set_matmul(self, mode: str):
+        """Matrix arithmetic of a float32 model's convolutions: "native" (exact f32 MFMA) or "f16x3" (split-f16, three passes)."""
+        if mode not in ops.MATH_MODES:
+            raise ValueError(f"matmul mode must be one of {sorted(ops.MATH_MODES)}")
+        if mode != self.matmul:
+            self.matmul = mode
+            self._plan = None
+            self.drop_graphs()
+        return self
+
     def convert_to_fp16(self):
-        """The reference's half-precision switch; on MI355X the low-precision operand type is bf16."""
-        return self.set_compute_dtype(torch.bfloat16)
+        """The reference's half-precision switch (src/fp16_util.py:15-22, src/unet_adm.py:620-626): IEEE half operands."""
+        return self.set_compute_dtype(torch.float16)
+
+    def half(self):
+        return self.set_compute_dtype(torch.float16)
 
     def convert_to_fp32(self):
         return self.set_compute_dtype(torch.float32)
@@ -214,7 +232,8 @@ class HipModule:
         if self._plan is None:
             self._require_gpu()
             with torch.cuda.device(self.device):
-                self._plan = self._build(self._sd, self.device, self.compute_dtype)
+                spec = F32X3 if (self.compute_dtype == torch.float32 and self.matmul == "f16x3") else self.compute_dtype
+                self._plan = self._build(self._sd, self.device, spec)
         return self._plan
 
     def _build(self, sd, device, dtype):
@@ -258,8 +277,27 @@ class Norm:
         return ops.conv2d(self(x, silu=silu, x1=x1, scale=scale, shift=shift), pw, **conv_kw)
 
 
-def pack(sd, p, dtype, device, **kw) -> ops.PackedConv:
-    return ops.pack_conv(sd[p + ".weight"], sd.get(p + ".bias"), dtype, device, **kw)
+class _F32X3:
+    """Compute spec handed to ``_build`` in place of a torch dtype: float32 storage, split-f16 matrix math in the convolutions
+    (weights packed as (hi, lo) halves).  Literal ``torch.float32`` in a ``_build`` (embedding MLPs, sigma head) stays exact."""
+
+    def __repr__(self):
+        return "float32/f16x3"
+
+
+F32X3 = _F32X3()
+
+
+def storage_dtype(spec) -> torch.dtype:
+    return torch.float32 if spec is F32X3 else spec
+
+
+def pack_w(weight, bias, spec, device, **kw) -> ops.PackedConv:
+    return ops.pack_conv(weight, bias, storage_dtype(spec), device, math="f16x3" if spec is F32X3 else "native", **kw)
+
+
+def pack(sd, p, spec, device, **kw) -> ops.PackedConv:
+    return pack_w(sd[p + ".weight"], sd.get(p + ".bias"), spec, device, **kw)
 
 
 class EmbBank:

@@ -2,7 +2,7 @@
 
 PyTorch is used here only as the owner of device memory and of the HIP stream; every
 arithmetic op below is a hand-written gfx950 kernel in libnlc_hip.so.  Activations are
-channels-last ``[B, H, W, C]`` tensors in the compute dtype (torch.float32 or torch.bfloat16).
+channels-last ``[B, H, W, C]`` tensors in the compute dtype (torch.float32, torch.bfloat16 or torch.float16).
 """
 from __future__ import annotations
 
@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _ext
-from ._ext import (ACT_GELU, ACT_NONE, ACT_SILU, NLC_BF16, NLC_F32, OUT_NCHW_F32, OUT_NHWC,
+from ._ext import (ACT_GELU, ACT_NONE, ACT_SILU, MATH_F16X3, MATH_NATIVE, NLC_BF16, NLC_F16, NLC_F32, OUT_NCHW_F32, OUT_NHWC,
                    ConvDesc, SchedDesc, check)
 
 
@@ -38,7 +38,16 @@ def dtype_enum(dtype: torch.dtype) -> int:
         return NLC_F32
     if dtype == torch.bfloat16:
         return NLC_BF16
-    raise TypeError(f"compute dtype must be float32 or bfloat16, got {dtype}")
+    if dtype == torch.float16:
+        return NLC_F16
+    raise TypeError(f"compute dtype must be float32, bfloat16 or float16, got {dtype}")
+
+
+def is16(dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16)
+
+
+MATH_MODES = {"native": MATH_NATIVE, "f16x3": MATH_F16X3}
 
 
 def _stream() -> int:
@@ -78,17 +87,20 @@ class PackedConv:
     Cin_pad: int
     Cout_pad: int
     dtype: torch.dtype
+    math: int = MATH_NATIVE           # MATH_F16X3: f32 tensor holding (hi, lo) f16 halves - nlc_conv2d must be told (desc.math)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype, device,
               row_perm: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
-              col_perm: Optional[torch.Tensor] = None, bias_add: Optional[torch.Tensor] = None) -> PackedConv:
+              col_perm: Optional[torch.Tensor] = None, bias_add: Optional[torch.Tensor] = None,
+              math: str = "native") -> PackedConv:
     """Pack a torch-layout weight ([Cout,Cin,KH,KW], [Cout,Cin,K] or [Cout,Cin]) once at load time, on the device,
     through nlc_pack_conv_weights (the layout, permutation and folding rules live behind the C ABI).
 
     row_perm / row_scale reorder and scale output channels (used to bring the reference's qkv
     channel orders into the canonical [3][H][D] order and to fold the attention scale or an eval-mode
     BatchNorm); bias_add is added to the (permuted, scaled) bias; col_perm reorders input features.
+    ``math="f16x3"`` (float32 only): pack for the split-f16 matrix mode (include/nlc_hip.h, NLC_MATH_F16X3).
     """
     lib = _ext.load()
     device = torch.device(device)
@@ -100,6 +112,9 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
     elif w.dim() == 3:
         w = w[:, :, :, None]
     Cout, Cin, KH, KW = w.shape
+    mcode = MATH_MODES[math]
+    if mcode != MATH_NATIVE and dtype != torch.float32:
+        raise TypeError("pack_conv: math='f16x3' is a mode of float32 tensors")
     cout_mult, cin_mult = _ext.pack_dims(dtype_enum(dtype))
     Cin_pad, Cout_pad = _round_up(Cin, cin_mult), _round_up(Cout, cout_mult)
     with torch.cuda.device(device):
@@ -115,10 +130,10 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
         packed = torch.empty(Cout_pad, KH * KW, Cin_pad, device=device, dtype=dtype)
         has_bias = bd is not None or ba is not None
         bout = torch.empty(Cout, device=device, dtype=torch.float32) if has_bias else None
-        check(lib.nlc_pack_conv_weights(wd.data_ptr(), _ptr(bd), Cout, Cin, KH, KW, _ptr(rp), _ptr(rs), _ptr(ba), _ptr(cp),
-                                        dtype_enum(dtype), packed.data_ptr(), _ptr(bout), _stream()), "nlc_pack_conv_weights")
+        check(lib.nlc_pack_conv_weights_ex(wd.data_ptr(), _ptr(bd), Cout, Cin, KH, KW, _ptr(rp), _ptr(rs), _ptr(ba), _ptr(cp),
+                                           dtype_enum(dtype), mcode, packed.data_ptr(), _ptr(bout), _stream()), "nlc_pack_conv_weights_ex")
         torch.cuda.current_stream().synchronize()      # load time: the f32 staging copies may be freed after this
-    return PackedConv(w=packed, bias=bout, Cin=Cin, Cout=Cout, KH=KH, KW=KW, Cin_pad=Cin_pad, Cout_pad=Cout_pad, dtype=dtype)
+    return PackedConv(w=packed, bias=bout, Cin=Cin, Cout=Cout, KH=KH, KW=KW, Cin_pad=Cin_pad, Cout_pad=Cout_pad, dtype=dtype, math=mcode)
 
 
 # --------------------------------------------------------------------------------------
@@ -132,6 +147,7 @@ CONV_PROFILE = None
 CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3, "wide": 4, "tall": 5}
 CONV_POLICY = "auto"
 CONV_TUNING = 0              # nlc_conv_desc.tuning: schedule A/B switches for tools/ (0 in production)
+CONV_DEBUG = 0               # nlc_conv_desc.debug: bit 0 = verify the split-K arrival counters before every split launch (tests)
 
 
 def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
@@ -199,7 +215,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
                  out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY], tuning=CONV_TUNING,
-                 res_upsample2x=1 if res_upsample2x else 0)
+                 res_upsample2x=1 if res_upsample2x else 0, math=pw.math, debug=CONV_DEBUG)
     if query_prologue:
         return bool(lib.nlc_conv2d_prologue_supported(C.byref(d), dtype_enum(dt)))
     if gn_coef is not None:
@@ -207,13 +223,13 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
             raise ValueError("conv2d: gn_coef must be a CUDA f32 [B, Cin, 2] table with >= 512 bytes of slack (groupnorm_coef)")
         d.gn_coef, d.gn_act = gn_coef.data_ptr(), gn_act
     stats = None
-    if dt == torch.bfloat16 and emit_stats and not out_nchw_f32 and not linear:
+    if is16(dt) and emit_stats and not out_nchw_f32 and not linear:
         # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel
         P = lib.nlc_conv2d_stats_partials(C.byref(d), dtype_enum(dt))
         if P > 0:
             stats = torch.empty(B, P, pw.Cout // 8, 2, device=x0.device, dtype=torch.float32)
             d.stats_out, d.stats_bytes = stats.data_ptr(), stats.numel() * 4
-    if dt == torch.bfloat16 or allow_split:      # split-K scratch for the few-tile / long-K levels (a cheap host query)
+    if is16(dt) or allow_split:      # split-K scratch for the few-tile / long-K levels (a cheap host query)
         need = lib.nlc_conv2d_workspace_bytes(C.byref(d), dtype_enum(dt))
         if need > 0:
             ws = _conv_workspace(x0.device, need)
@@ -223,17 +239,33 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         # bench.py's roofline leg: HIP events on the launch stream around this one kernel
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
+        _launch_conv(lib, d, dt)
         e1.record()
         prof.append((e0, e1, 2.0 * B * Hout * Wout * pw.Cout * pw.KH * pw.KW * pw.Cin, dt,
                      (B * Hout * Wout, pw.Cout, pw.KH * pw.KW, pw.Cin, stride, int(upsample2x), C1)))
     else:
-        check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
+        _launch_conv(lib, d, dt)
     if linear and not out_nchw_f32:
         out = out.view(B, pw.Cout)
     if stats is not None:
         out._nlc_stats = stats                  # consumed by groupnorm(); lives and dies with this tensor object
     return out
+
+
+def _launch_conv(lib, d: ConvDesc, dt: torch.dtype) -> None:
+    try:
+        check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
+    except _ext.NlcError:
+        if d.workspace:
+            # a split-K launch that did not complete may leave arrival counters non-zero, and every later split launch on this
+            # workspace would then reduce early or never: drop the workspace, the next call allocates a zeroed one
+            reset_conv_workspaces()
+        raise
+
+
+def reset_conv_workspaces() -> None:
+    """Forget every split-K workspace (they are re-allocated zeroed on demand).  Called after a failed nlc_conv2d."""
+    _conv_ws.clear()
 
 
 def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
@@ -310,7 +342,7 @@ def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
         if shift.stride(0) != ss_stride:
             raise ValueError("groupnorm: scale/shift must share a row stride")
     ws = _gn_workspace(x0.device, lib.nlc_groupnorm_workspace_bytes(B, HW, Ctot, groups))
-    if FUSED_GN_STATS and dt == torch.bfloat16 and (Ctot // groups) % 8 == 0 and C0 % 8 == 0 and Ctot // 8 <= 256:
+    if FUSED_GN_STATS and is16(dt) and (Ctot // groups) % 8 == 0 and C0 % 8 == 0 and Ctot // 8 <= 256:
         s0 = getattr(x0, "_nlc_stats", None)
         s1 = getattr(x1, "_nlc_stats", None) if x1 is not None else None
         if s0 is not None and (x1 is None or s1 is not None):
@@ -348,7 +380,7 @@ def groupnorm_pool2x2(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Opti
             raise ValueError("groupnorm_pool2x2: scale/shift must share a row stride")
     ws = _gn_workspace(x.device, lib.nlc_groupnorm_workspace_bytes(B, H * W, Cc, groups))
     s0 = None
-    if FUSED_GN_STATS and dt == torch.bfloat16 and (Cc // groups) % 8 == 0:
+    if FUSED_GN_STATS and is16(dt) and (Cc // groups) % 8 == 0:
         s0 = getattr(x, "_nlc_stats", None)
     check(lib.nlc_groupnorm_pool2x2(x.data_ptr(), Cc, B, H, W, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift),
                                     ss_stride, 1 if silu else 0, out_h.data_ptr(), out_x.data_ptr(), ws.data_ptr(), dtype_enum(dt),
@@ -360,7 +392,7 @@ FUSE_GN_POOL = True        # networks: down-sampling ResBlocks use groupnorm_poo
 
 
 def groupnorm_pool2x2_supported(x: torch.Tensor) -> bool:
-    per = 8 if x.dtype == torch.bfloat16 else 4
+    per = 8 if is16(x.dtype) else 4
     return FUSE_GN_POOL and x.dim() == 4 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % per == 0 and x.shape[3] // per <= 256
 
 
@@ -377,7 +409,7 @@ def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1
     with the producing convolutions - for conv2d(gn_coef=...).  None when they are not available (f32 models, inputs without
     attached statistics, group sizes that 8-channel chunks cannot express): the caller then runs groupnorm()."""
     lib = _ext.load()
-    if not FUSED_GN_STATS or x0.dtype != torch.bfloat16:
+    if not FUSED_GN_STATS or x0.dtype != torch.bfloat16:     # (the LDS prologue exists for bf16 only)
         return None
     B, C0 = x0.shape[0], x0.shape[-1]
     C1 = 0 if x1 is None else x1.shape[-1]
@@ -556,8 +588,14 @@ def lincomb_rows(x: torch.Tensor, ca: torch.Tensor, y: Optional[torch.Tensor] = 
     _need(x, torch.float32, "lincomb_rows x")
     B = x.shape[0]
     out = torch.empty_like(x)
+    if ca.numel() != B or (cb is not None and cb.numel() != B):
+        raise ValueError(f"lincomb_rows: coefficient vectors must have one entry per row ({B})")
+    if (y is None) != (cb is None):
+        raise ValueError("lincomb_rows: y and cb come together")
     if y is not None:
         _need(y, torch.float32, "lincomb_rows y")
+        if y.shape != x.shape:
+            raise ValueError(f"lincomb_rows: y has shape {tuple(y.shape)}, x {tuple(x.shape)}")
     check(lib.nlc_lincomb_rows(x.data_ptr(), _need(ca, torch.float32, "lincomb_rows ca").data_ptr(), _ptr(y),
                                None if cb is None else _need(cb, torch.float32, "lincomb_rows cb").data_ptr(), out.data_ptr(), B,
                                x.numel() // B, _stream()), "nlc_lincomb_rows")

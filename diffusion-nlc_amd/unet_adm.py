@@ -243,7 +243,7 @@ class UNetModel(HipModule):
         P.inp = [make(l) for l in blocks_in]
         P.mid = make(mid)
         P.out = [make(l) for l in blocks_out]
-        bank.finalize(device, allow_split=dtype == torch.bfloat16)
+        bank.finalize(device, allow_split=ops.is16(dtype))
         P.bank = bank
         P.out_norm = Norm(sd, "out.0", device, GN_GROUPS, GN_EPS)
         P.out_conv = pack(sd, "out.2", dtype, device)
@@ -252,7 +252,7 @@ class UNetModel(HipModule):
     # ---- execution -----------------------------------------------------------------------------
     def _emb(self, P, t, y=None):
         temb = ops.timestep_embedding(t, P.freqs, sin_first=False)          # cos || sin
-        sp = self.compute_dtype == torch.bfloat16                            # f32 GEMMs of a bf16 model may split K
+        sp = ops.is16(self.compute_dtype)                            # f32 GEMMs of a bf16 model may split K
         e = ops.conv2d(temb, P.te0, act=ACT_SILU, allow_split=sp)            # Linear -> SiLU
         # emb = time_embed(...) + label_emb(y) (src/unet_adm.py:650-654): the gathered embedding rows ride in the GEMM's
         # per-image add; every consumer starts with SiLU(emb), applied here once
@@ -391,7 +391,7 @@ class SigmaModel(HipModule):
             P.blocks.append((pad, _ResBlock(sd, res, dtype, device, None, False),
                              _Attention(sd, attn, dtype, device, self.heads, self.new_order) if attn else None,
                              pack(sd, down + ".op", dtype, device)))
-        P.head = SigmaHead(sd, device, ACT_GELU, allow_split=dtype == torch.bfloat16)
+        P.head = SigmaHead(sd, device, ACT_GELU, allow_split=ops.is16(dtype))
         return P
 
     def run_nhwc(self, h: torch.Tensor) -> torch.Tensor:

@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from ._ext import ACT_GELU, ACT_NONE, ACT_SILU
-from .hipnet import EmbBank, HipModule, Norm, SigmaHead, SpecBuilder, as_f32_cuda, first_conv_weight, pack
+from .hipnet import EmbBank, HipModule, Norm, SigmaHead, SpecBuilder, as_f32_cuda, first_conv_weight, pack, pack_w
 
 GN_GROUPS, GN_EPS = 32, 1e-6       # Normalize (src/unet_simple.py:32-33)
 
@@ -66,7 +66,7 @@ class _AttnBlock:
         b = torch.cat([sd[f"{p}.{n}.bias"] for n in ("q", "k", "v")], 0)
         scale = torch.ones(3 * c)
         scale[: 2 * c] = float(c) ** -0.25                  # w_ * c^-1/2 (:177) split evenly over q and k
-        self.qkv = ops.pack_conv(w, b, dtype, device, row_scale=scale)
+        self.qkv = pack_w(w, b, dtype, device, row_scale=scale)
         self.proj = pack(sd, p + ".proj_out", dtype, device)
 
     def __call__(self, x):
@@ -176,7 +176,7 @@ class Model(HipModule):
         P.up = [([(mk(p), _AttnBlock(sd, a, dtype, device) if a else None) for p, ci, co, a in blocks],
                  (pack(sd, us + ".conv", dtype, device) if self.resamp_with_conv else "nearest") if us else None)
                 for lvl, blocks, us, cin in up]
-        bank.finalize(device, allow_split=dtype == torch.bfloat16)
+        bank.finalize(device, allow_split=ops.is16(dtype))
         P.bank = bank
         P.norm_out = Norm(sd, "norm_out", device, GN_GROUPS, GN_EPS)
         P.conv_out = pack(sd, "conv_out", dtype, device)
@@ -288,7 +288,7 @@ class SigmaModel(HipModule):
         layout, _ = self._layout()
         P.blocks = [(pad, _ResnetBlock(sd, res, dtype, device, None), _AttnBlock(sd, attn, dtype, device) if attn else None,
                      pack(sd, down + ".conv", dtype, device)) for pad, res, attn, down in layout]
-        P.head = SigmaHead(sd, device, ACT_GELU, allow_split=dtype == torch.bfloat16)
+        P.head = SigmaHead(sd, device, ACT_GELU, allow_split=ops.is16(dtype))
         return P
 
     def run_nhwc(self, h):

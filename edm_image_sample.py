@@ -69,7 +69,8 @@ def get_args(argv=None):
     a("--norm_min", type=float, default=0.0)
     # extensions
     a("--synthetic", type=str, default=None, choices=sorted(SYNTHETIC))
-    a("--dtype", type=str, default="f32", choices=["f32", "bf16"])
+    a("--dtype", type=str, default="f32", choices=["f32", "f32x3", "bf16", "f16"],
+      help="HIP-path precision (not a reference flag): f32 = exact f32 MFMA, f32x3 = f32 storage + split-f16 matrix math, bf16 / f16")
     return p.parse_args(argv)
 
 
@@ -97,11 +98,12 @@ def main(args):
     else:
         model.load_state_dict(torch.load(args.load_eps, map_location="cpu"))
         sigma_model.load_state_dict(torch.load(args.load_sigma, map_location="cpu"))
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dt, mm = {"f32": (torch.float32, "native"), "f32x3": (torch.float32, "f16x3"), "bf16": (torch.bfloat16, "native"),
+              "f16": (torch.float16, "native")}[args.dtype]
     if torch.device(args.device).type == "cuda":
         torch.cuda.set_device(torch.device(args.device))       # --device cuda:K: every launch below goes to K's streams
-    model.eval().to(args.device).set_compute_dtype(dt)
-    sigma_model.eval().to(args.device).set_compute_dtype(dt)
+    model.eval().to(args.device).set_compute_dtype(dt).set_matmul(mm)
+    sigma_model.eval().to(args.device).set_compute_dtype(dt).set_matmul(mm)
 
     res, ch = cfg["img_resolution"], cfg["in_channels"]
     exp = EDMImageExperiment(model, None, batch_size=args.batch_size, data_shape=(ch, res, res), seed=args.seed,

@@ -111,6 +111,9 @@ def build_parser():
     a("--recal_sigma_prev", type=int, default=1)
     a("--batch_size", type=int, default=10)
     a("--device", type=str, default="cuda:0")
+    a("--precision", type=str, default="", choices=["", "f32", "f32x3", "bf16", "f16"],
+      help="HIP-path precision override (not a reference flag).  Default: the model config decides as upstream - use_fp16 -> f16 "
+           "operands, else f32.  f32x3 = f32 storage + split-f16 three-pass matrix math (inside 1e-3 of the CPU path, ~3x f32's speed)")
     a("--seed", type=int, default=1234)
     a("--result_dir", type=str, default="results")
     a("--test_dir", type=str, default="temp2")
@@ -379,6 +382,11 @@ def main(args, config):
         model.convert_to_fp16()
     if getattr(mc, "use_sigma_fp16", False):
         sigma_model.convert_to_fp16()
+    if getattr(args, "precision", ""):
+        dt, mm = {"f32": (torch.float32, "native"), "f32x3": (torch.float32, "f16x3"), "bf16": (torch.bfloat16, "native"),
+                  "f16": (torch.float16, "native")}[args.precision]
+        for m in (model, sigma_model):
+            m.set_compute_dtype(dt).set_matmul(mm)
 
     dc = config.diffusion
     sampler = get_sampler(args.sampler, dc.num_diffusion_timesteps, args.num_timesteps, beta_schedule=dc.beta_schedule,

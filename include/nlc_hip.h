@@ -13,7 +13,10 @@
  *  - All pointers are BORROWED device pointers (hipMalloc'ed / torch caching allocator).
  *    The caller keeps them alive until `stream` has passed the launch.
  *  - `stream` is a hipStream_t passed as void* (0 = the null stream).
- *  - dtype: NLC_F32 (exact f32 MFMA path) or NLC_BF16 (bf16 operands, f32 accumulate).
+ *  - dtype = storage type of activations and packed weights: NLC_F32 (exact f32 MFMA path), NLC_BF16 or NLC_F16
+ *    (16-bit operands, f32 accumulate; v_mfma_f32_16x16x32_{bf16,f16} run at the same rate on gfx950).  NLC_F16 is the
+ *    reference's own half-precision mode (src/fp16_util.py:15-22, src/unet_adm.py:620-634).  On NLC_F32 tensors the
+ *    convolutions can additionally run in NLC_MATH_F16X3 (nlc_conv_desc.math): f32 storage, split-f16 matrix math.
  *  - Activations are channels-last: [B][H][W][C] ("NHWC"); token tensors are [B][T][C].
  *    Weights are pre-packed by the host into [Cout_pad][KH*KW][Cin_pad] (see
  *    nlc_conv_pack_dims) in the compute dtype.
@@ -27,9 +30,16 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 3
+#define NLC_ABI_VERSION 4
 
-enum { NLC_F32 = 0, NLC_BF16 = 1 };
+enum { NLC_F32 = 0, NLC_BF16 = 1, NLC_F16 = 2 };
+/* matrix arithmetic of nlc_conv2d on NLC_F32 tensors (nlc_conv_desc.math; weights must be packed for the same mode):
+ *   NLC_MATH_NATIVE  the dtype's own MFMA (f32: exact v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit rate)
+ *   NLC_MATH_F16X3   every f32 operand x is split into two halves, hi = f16(x), lo = f16(x - hi) (22 significand bits
+ *                    between them), and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with f32 accumulate:
+ *                    3/16 of the 16-bit rate instead of 1/16, relative error per product <= 2^-21.  Storage, bias, embedding,
+ *                    residual, activation and every non-convolution kernel stay exact f32. */
+enum { NLC_MATH_NATIVE = 0, NLC_MATH_F16X3 = 1 };
 enum { NLC_OK = 0, NLC_EINVAL = -1, NLC_ELAUNCH = -2, NLC_EUNSUPPORTED = -3 };
 enum { NLC_ACT_NONE = 0, NLC_ACT_SILU = 1, NLC_ACT_GELU = 2 };
 enum { NLC_OUT_NHWC = 0, NLC_OUT_NCHW_F32 = 1 };
@@ -51,11 +61,12 @@ enum { NLC_VAR_NONE = 0, NLC_VAR_FIXEDSMALL = 1, NLC_VAR_FIXEDLARGE = 2, NLC_VAR
  * timings can pin a kernel per call; there is no process-wide switch. */
 enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3, NLC_CONV_FORCE_WIDE = 4,
        NLC_CONV_FORCE_TALL = 5 };
-/* (FORCE_WIDE: the 512-pixel x 128-channel variant of the halo kernel, csrc/conv_wide.hip - opt-in only: it measured level
- *  with the 256-pixel kernel on 256^2 maps and slower below, so AUTO never selects it; shapes it does not support fall through
- *  to the AUTO order.  FORCE_TALL: the 256-pixel x 256-channel variant, csrc/conv_tall.hip) */
+/* (FORCE_WIDE / FORCE_TALL select two experimental tile shapes of the halo kernel, csrc/experiments/conv_{wide,tall}.hip.  They
+ *  are NOT part of the shipped library: only a `csrc/build.sh --experiments` build contains them (nlc_has_experiments() == 1);
+ *  without it nlc_conv2d rejects the two policies with NLC_EUNSUPPORTED.  AUTO never selects them.) */
 
 int nlc_version(void);
+int nlc_has_experiments(void);   /* 1: built with --experiments (conv_wide / conv_tall present), 0: the shipped library */
 const char* nlc_last_error(void);
 
 /* Tile geometry the host needs to pack weights: Cout is padded to a multiple of
@@ -81,6 +92,13 @@ int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult);
 int nlc_pack_conv_weights(const float* w, const float* bias, int Cout, int Cin, int KH, int KW,
                           const int32_t* row_perm, const double* row_scale, const double* bias_add,
                           const int32_t* col_perm, int dtype, void* packed, float* bias_out, void* stream);
+/* same with the matrix-arithmetic mode the weights will be used with (nlc_conv_desc.math).  math = NLC_MATH_F16X3 (dtype must
+ * be NLC_F32): every 32-channel k-block (128 bytes) of a packed row holds, per 16-byte chunk c = 0..3, the f16 `hi` halves of
+ * channels 4c..4c+3 and 16+4c..16+4c+3 (the 8 k-values one lane feeds to a 16x16x32 MFMA), and chunk 4+c the `lo` halves of the
+ * same channels; hi = f16(x) rounded to nearest, lo = f16(x - hi). */
+int nlc_pack_conv_weights_ex(const float* w, const float* bias, int Cout, int Cin, int KH, int KW,
+                             const int32_t* row_perm, const double* row_scale, const double* bias_add,
+                             const int32_t* col_perm, int dtype, int math, void* packed, float* bias_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Convolution / linear as one implicit-GEMM MFMA kernel.
@@ -133,6 +151,11 @@ typedef struct nlc_conv_desc {
     int32_t res_upsample2x; /* 1: res is [B][Hout/2][Wout/2][Cout] and output pixel (y, x) adds res pixel (y/2, x/2) - the        */
                          /* skip branch x_upd(x) of an up-sampling ResBlock (src/unet_adm.py:186-190, nearest-2x Upsample) read    */
                          /* in place of a materialised upsampled copy.  Hout, Wout must be even.                                  */
+    int32_t math;        /* NLC_MATH_* (0 = the dtype's native MFMA).  NLC_MATH_F16X3 needs dtype NLC_F32 and `w` packed by          */
+                         /* nlc_pack_conv_weights_ex(..., NLC_MATH_F16X3): the packed tensor then holds (hi, lo) f16 halves of every  */
+                         /* weight in the k order the kernels read, same byte size as the f32 packing.                                 */
+    int32_t debug;       /* 0 in production.  Bit 0: before launching a split-K shape, copy the workspace's arrival counters back and   */
+                         /* return NLC_EINVAL if any is non-zero (a poisoned workspace; synchronises the stream - tests / triage only). */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);

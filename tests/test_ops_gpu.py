@@ -1,10 +1,12 @@
 """Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch-CPU f32 ops.
 
-Tolerances: f32 path 2e-4 relative-to-scale (different summation order only); bf16 path is
-compared with the same op evaluated in f32 on bf16-rounded operands, tolerance 2e-2 (output
-rounding to bf16 + f32-accumulate order).
+Tolerances: f32 path 2e-4 relative-to-scale (different summation order only); the 16-bit paths are
+compared with the same op evaluated in f32 on operands rounded to that type: bf16 2e-2, f16 3e-3 (output
+rounding to 8 / 11 significand bits + f32-accumulate order).  The split-f16 matrix mode of f32 tensors
+(NLC_MATH_F16X3) is compared with an f64 evaluation on the EXACT operands at 5e-6.
 """
 import math
+import zlib
 
 import pytest
 import torch
@@ -12,7 +14,25 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+DTYPE_IDS = ["f32", "bf16", "f16"]
+T16 = [torch.bfloat16, torch.float16]
+T16_IDS = ["bf16", "f16"]
+
+
+def _seed(obj) -> int:
+    """A seed that is the same in every process (hash() of a str is salted per interpreter)."""
+    return zlib.crc32(repr(obj).encode()) & 0x7fffffff
+
+
+def _has_experiments() -> bool:
+    from diffusion_nlc_amd import _ext
+    return bool(_ext.load().nlc_has_experiments())
+
+
+def _need_experiments():
+    if not _has_experiments():
+        pytest.skip("conv_wide / conv_tall are only in a `csrc/build.sh --experiments` build (not the shipped library)")
 
 
 def _dev():
@@ -20,7 +40,7 @@ def _dev():
 
 
 def _tol(dtype):
-    return 2e-4 if dtype == torch.float32 else 2e-2
+    return {torch.float32: 2e-4, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
 
 
 def _rt(x, dtype):
@@ -66,7 +86,7 @@ CONV_CASES = [
     # > 256 tiles: every persistent workgroup walks 2 tiles (cross-tile DMA streams, accumulator re-init, both N-tiles)
     dict(B=1, Cin=64, H=256, W=256, Cout=256, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
     dict(B=2, Cin=128, H=256, W=128, Cout=256, k=3, split=64, act="silu"),
-    # few output tiles + long K: split-K in bf16 (2 / 4 / 2 splits), partials reduced in a second kernel
+    # few output tiles + long K: split-K in the 16-bit types (2 / 4 / 2 splits), partials reduced by the last-arriving workgroup
     dict(B=2, Cin=256, H=8, W=8, Cout=128, k=3, emb=True, res=True, scale=math.sqrt(0.5)),
     dict(B=1, Cin=512, H=8, W=8, Cout=72, k=3, act="silu", nchw=True),
     dict(B=2, Cin=1024, H=4, W=4, Cout=256, k=1, res=True),
@@ -80,11 +100,9 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d(case, dtype, conv_policy):
+def _run_conv_case(case, dtype, math_mode="native"):
     from diffusion_nlc_amd import ops
-    g = torch.Generator().manual_seed(hash(str(case)) % (1 << 31))
+    g = torch.Generator().manual_seed(_seed(case))
     B, Cin, H, W, Cout, k = (case[x] for x in ("B", "Cin", "H", "W", "Cout", "k"))
     stride, pad = case.get("stride", 1), case.get("pad", k // 2)
     per = 4 if dtype == torch.float32 else 8
@@ -92,6 +110,9 @@ def test_conv2d(case, dtype, conv_policy):
     w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
     b = torch.randn(Cout, generator=g) * 0.1 if case.get("bias", True) else None
     xr, wr = _rt(x, dtype), _rt(w, dtype)
+    x3 = math_mode == "f16x3"
+    if x3:                    # reference in f64 on the exact operands: the mode claims near-f32 accuracy, not f16 accuracy
+        xr, wr, b = x.double(), w.double(), None if b is None else b.double()
     xin = F.interpolate(xr, scale_factor=2, mode="nearest") if case.get("ups") else xr
     if case.get("asym"):
         xin = F.pad(xin, (0, 1, 0, 1))
@@ -109,8 +130,9 @@ def test_conv2d(case, dtype, conv_policy):
         ref = F.silu(ref)
     elif act == 2:
         ref = F.gelu(ref)
+    ref = ref.float()
 
-    pw = ops.pack_conv(w, b, dtype, _dev())
+    pw = ops.pack_conv(w, None if b is None else b.float(), dtype, _dev(), math=math_mode)
     split = case.get("split")
     if split and split % per:
         pytest.skip("split not aligned for this dtype")
@@ -123,10 +145,51 @@ def test_conv2d(case, dtype, conv_policy):
     torch.cuda.synchronize()
     if not case.get("nchw"):
         got = got.permute(0, 3, 1, 2)
-    _close(got, ref, _tol(dtype), "conv2d")
+    _close(got, ref, 5e-6 if x3 else _tol(dtype), "conv2d" + (" (f16x3)" if x3 else ""))
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d(case, dtype, conv_policy):
+    _run_conv_case(case, dtype)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_split_f16_math(case, conv_policy):
+    """NLC_MATH_F16X3 on f32 tensors: every kernel that can take the launch (halo kernel with the in-LDS operand split, conv_fast
+    with the in-register split, the generic kernel rebuilding hi + lo) against an f64 reference on the exact operands."""
+    _run_conv_case(case, torch.float32, "f16x3")
+
+
+@pytest.mark.parametrize("policy", ["auto", "halo", "no_halo", "generic"])
+def test_split_f16_math_carries_22_bits(policy):
+    """Adversarial operands for the operand split: magnitudes over 12 binades on both sides (the lo halves of the small ones are f16
+    subnormals), one input channel block where only lo halves are non-zero (values below half an f16 ulp of nothing: exact powers of
+    two times (1 + 2^-12)), against f64.  A kernel that dropped a cross term, flushed subnormal halves or mis-paired hi / lo lanes
+    fails this by orders of magnitude (bf16: 4e-3, plain f16: 5e-4, this mode: < 2e-6)."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(123)
+    B, Cin, H, W, Cout = 2, 64, 16, 16, 128
+    mag = torch.exp2(torch.randint(-8, 4, (B, Cin, H, W), generator=g).float())
+    x = torch.randn(B, Cin, H, W, generator=g) * mag
+    x[:, 32:48] = (1 + 2.0 ** -12) * torch.exp2(torch.randint(-3, 3, (B, 16, H, W), generator=g).float())     # hi = 2^k, lo = 2^(k-12)
+    wmag = torch.exp2(torch.randint(-10, 0, (Cout, Cin, 3, 3), generator=g).float())
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * wmag
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = policy
+    try:
+        got = ops.conv2d(_nhwc(x, torch.float32), ops.pack_conv(w, None, torch.float32, _dev(), math="f16x3"))
+        exact = ops.conv2d(_nhwc(x, torch.float32), ops.pack_conv(w, None, torch.float32, _dev()))
+    finally:
+        ops.CONV_POLICY = old
+    scale = ref.abs().max().item()
+    e3 = (got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() / scale
+    e1 = (exact.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() / scale
+    assert e3 < 2e-6, f"f16x3 under policy {policy}: {e3:.3e} (exact-f32 MFMA on the same data: {e1:.3e})"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_linear(dtype):
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(7)
@@ -152,7 +215,7 @@ GN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("case", GN_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_groupnorm(case, dtype):
     from diffusion_nlc_amd import ops
@@ -191,7 +254,7 @@ GNPOOL_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("case", GNPOOL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_groupnorm_pool2x2(case, dtype):
     """nlc_groupnorm_pool2x2 = (AvgPool2d(2)(act(GroupNorm(x))), AvgPool2d(2)(x)) - both branches of a down-sampling ResBlock
@@ -260,7 +323,7 @@ ATTN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_attention(case, dtype):
     from diffusion_nlc_amd import ops
@@ -282,7 +345,7 @@ def test_attention(case, dtype):
     _close(got, ref, _tol(dtype) * (1 if dtype == torch.float32 else 1.5), "attention")
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_resample_and_layout(dtype):
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -313,7 +376,7 @@ def test_timestep_embedding():
     assert (got.cpu() - torch.cat([torch.sin(args), torch.cos(args)], dim=-1)).abs().max().item() < 2e-6
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 def test_conv_first(dtype):
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(9)
@@ -324,7 +387,7 @@ def test_conv_first(dtype):
     ref = F.conv2d(x * sc[:, None, None, None], w, b, padding=1)
     wp = w.permute(0, 2, 3, 1).reshape(40, 9, 3).contiguous().to(_dev())
     got = ops.conv_first(x.to(_dev()), wp, b.to(_dev()), dtype, in_scale=sc.to(_dev()))
-    _close(got.permute(0, 3, 1, 2), ref, 1e-5 if dtype == torch.float32 else 1e-2, "conv_first")
+    _close(got.permute(0, 3, 1, 2), ref, {torch.float32: 1e-5, torch.bfloat16: 1e-2, torch.float16: 2e-3}[dtype], "conv_first")
     # ADM-like first layer: whole 64-pixel tiles, 256 channels -> bf16 takes the matrix-core kernel and emits
     # GroupNorm statistics of the stored output
     x = torch.randn(2, 3, 32, 64, generator=g)
@@ -333,9 +396,9 @@ def test_conv_first(dtype):
     ref = F.conv2d(x * sc[:, None, None, None], w, b, padding=1)
     wp = w.permute(0, 2, 3, 1).reshape(256, 9, 3).contiguous().to(_dev())
     got = ops.conv_first(x.to(_dev()), wp, b.to(_dev()), dtype, in_scale=sc.to(_dev()))
-    _close(got.permute(0, 3, 1, 2), ref, 1e-5 if dtype == torch.float32 else 1e-2, "conv_first 256")
+    _close(got.permute(0, 3, 1, 2), ref, {torch.float32: 1e-5, torch.bfloat16: 1e-2, torch.float16: 2e-3}[dtype], "conv_first 256")
     st = getattr(got, "_nlc_stats", None)
-    assert (st is not None) == (dtype == torch.bfloat16)
+    assert (st is not None) == (dtype != torch.float32)
     if st is not None:
         ch = got.float().cpu().view(2, 32 * 64, 32, 8)
         assert (st.double().sum(1).cpu()[..., 0] - ch.double().sum(dim=(1, 3))).abs().max() < 5e-2
@@ -364,7 +427,8 @@ def test_row_sumsq_and_quantile():
     assert torch.equal(ops.dynamic_threshold(z.to(_dev()), 0.99, 100.0).cpu(), torch.tensor([3.0, 3.0]))
 
 
-def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy, t16):
     """bf16 conv (LDS-halo kernel when forced, conv_fast<9> under the production dispatch): the epilogue's per-8-channel
     (sum, sumsq) partials describe the STORED output exactly enough, and GroupNorm fed with them (two passes) agrees with the
     three-pass GroupNorm and with the f32 reference."""
@@ -375,8 +439,8 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
     b = torch.randn(Cout, generator=g) * 0.3 + 0.5                    # non-zero mean: E[x^2]-E[x]^2 is exercised
     res = torch.randn(B, Cout, H, W, generator=g)
-    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
-    y = ops.conv2d(_nhwc(x, torch.bfloat16), pw, res=_nhwc(res, torch.bfloat16), act=1)
+    pw = ops.pack_conv(w, b, t16, _dev())
+    y = ops.conv2d(_nhwc(x, t16), pw, res=_nhwc(res, t16), act=1)
     st = getattr(y, "_nlc_stats", None)
     # partials per image: 4 per 16x16 patch from the halo kernel, 2 per 128-pixel tile from conv_fast
     P = (H // 16) * (W // 16) * 4 if conv_policy == "halo" else (H * W // 128) * 2
@@ -390,7 +454,7 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
     assert ((got[..., 1] - ref_sq) / ref_sq).abs().max() < 5e-4
     # a second conv makes the skip source of a concatenated GroupNorm input; 384 channels / 32 groups = 12: not a
     # multiple of 8 -> falls back; 256 + 256 = 512 -> group size 16, fused
-    y2 = ops.conv2d(_nhwc(x, torch.bfloat16), pw)
+    y2 = ops.conv2d(_nhwc(x, t16), pw)
     gamma, beta = torch.randn(2 * Cout, generator=g).to(_dev()), torch.randn(2 * Cout, generator=g).to(_dev())
     fused = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=True, x1=y2)
     ops.FUSED_GN_STATS = False
@@ -401,7 +465,7 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy):
     # split-K shape (8x8 level; not halo-eligible): the statistics come from the last-arriving split workgroup, one partial per pixel
     xs = torch.randn(2, 512, 8, 8, generator=g)
     ws = torch.randn(256, 512, 3, 3, generator=g) / math.sqrt(512 * 9)
-    ys = ops.conv2d(_nhwc(xs, torch.bfloat16), ops.pack_conv(ws, b, torch.bfloat16, _dev()))
+    ys = ops.conv2d(_nhwc(xs, t16), ops.pack_conv(ws, b, t16, _dev()))
     sts = getattr(ys, "_nlc_stats", None)
     assert sts is not None and sts.shape == (2, 64, 32, 2)
     chs = ys.float().cpu().view(2, 64, 32, 8)
@@ -425,8 +489,9 @@ STAT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
 @pytest.mark.parametrize("case", STAT_CASES, ids=lambda c: f"B{c[0]}-Cin{c[1]}-{c[2]}x{c[3]}-Cout{c[4]}")
-def test_ride_along_statistics_under_the_production_dispatch(case):
+def test_ride_along_statistics_under_the_production_dispatch(case, t16):
     """The statistics every bf16 GroupNorm of the benchmarked path consumes, from each kernel that emits them under the
     PRODUCTION dispatch (ops.groupnorm trusts the attached buffer blindly): sums over partials == sums over the stored
     output, for every 8-channel chunk; then GroupNorm with and without them."""
@@ -440,12 +505,12 @@ def test_ride_along_statistics_under_the_production_dispatch(case):
     old = ops.CONV_POLICY
     ops.CONV_POLICY = "auto"
     try:
-        y = ops.conv2d(_nhwc(x, torch.bfloat16), ops.pack_conv(w, b, torch.bfloat16, _dev()), res=_nhwc(res, torch.bfloat16))
+        y = ops.conv2d(_nhwc(x, t16), ops.pack_conv(w, b, t16, _dev()), res=_nhwc(res, t16))
     finally:
         ops.CONV_POLICY = old
     st = getattr(y, "_nlc_stats", None)
     assert st is not None and st.shape == (B, P_expect, Cout // 8, 2), (what, None if st is None else st.shape)
-    ref = F.conv2d(_rt(x, torch.bfloat16), _rt(w, torch.bfloat16), b, padding=1) + _rt(res, torch.bfloat16)
+    ref = F.conv2d(_rt(x, t16), _rt(w, t16), b, padding=1) + _rt(res, t16)
     _close(y.permute(0, 3, 1, 2), ref, 2e-2, what)
     ch = y.float().cpu().view(B, H * W, Cout // 8, 8).double()
     got = st.double().sum(dim=1).cpu()
@@ -599,7 +664,8 @@ HALOSPLIT_CASES = [
 
 
 @pytest.mark.parametrize("case", HALOSPLIT_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d_halo_kernel_split_k(case):
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+def test_conv2d_halo_kernel_split_k(case, t16):
     """conv_halo_kernel<bf16, false, SPLIT> under the production dispatch: launches with fewer tiles than CUs; raw f32 partial sums per
     channel-block range, reduced in split order by whichever workgroup arrives last at the tile, which then runs the normal epilogue
     (bias / embedding / residual / statistics).  Deterministic: two runs are bit-identical."""
@@ -612,22 +678,22 @@ def test_conv2d_halo_kernel_split_k(case):
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
     b = torch.randn(Cout, generator=g) * 0.1
-    xr = _rt(x, torch.bfloat16)
+    xr = _rt(x, t16)
     xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups else xr
-    ref = F.conv2d(xin, _rt(w, torch.bfloat16), b, padding=1)
+    ref = F.conv2d(xin, _rt(w, t16), b, padding=1)
     emb = res = None
     if case.get("emb"):
         emb = torch.randn(B, Cout, generator=g)
         ref = ref + emb[:, :, None, None]
     if case.get("res"):
         res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
-        ref = ref + _rt(res, torch.bfloat16)
+        ref = ref + _rt(res, t16)
     ref = ref * case.get("scale", 1.0)
-    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    pw = ops.pack_conv(w, b, t16, _dev())
     split = case.get("split")
-    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
-    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
-    kw = dict(x1=x1, upsample2x=ups, emb=None if emb is None else emb.to(_dev()), res=None if res is None else _nhwc(res, torch.bfloat16),
+    x0 = _nhwc(x[:, :split] if split else x, t16)
+    x1 = _nhwc(x[:, split:], t16) if split else None
+    kw = dict(x1=x1, upsample2x=ups, emb=None if emb is None else emb.to(_dev()), res=None if res is None else _nhwc(res, t16),
               out_scale=case.get("scale", 1.0))
     old = ops.CONV_POLICY
     ops.CONV_POLICY = "auto"
@@ -678,9 +744,91 @@ def test_split_k_launches_leave_the_arrival_counters_zero():
         ops.CONV_POLICY = old
 
 
+def test_split_k_stress():
+    """2 000 back-to-back split-K launches, mixed kernels and levels (halo kernel on the 16x16 level, conv_fast<9> on the 8x8 level,
+    conv_fast<1>), through ONE workspace, half of them beside a second stream that keeps the memory system busy: every result is
+    bit-identical to the first one of its shape, which is bit-identical to the formally fenced variant (tuning bit 10: agent-scope
+    release before the arrival add, acquire in the last arriver) and agrees with the un-split kernel (tuning bit 11) to rounding.
+    The hand-off rests on measured sc1 write-through / L1-bypass behaviour (conv_halo.hip), not on the HIP memory model: a
+    visibility failure would show up here as a mismatch, not a crash."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(77)
+    shapes = [(16, 1024, 16, 16, 1024, 3), (16, 2048, 16, 16, 1024, 3), (16, 1024, 8, 8, 1024, 3), (16, 2048, 8, 8, 1024, 3),
+              (16, 1024, 8, 8, 3072, 1), (16, 512, 16, 16, 1024, 3)]
+    old_p, old_t, old_d = ops.CONV_POLICY, ops.CONV_TUNING, ops.CONV_DEBUG
+    ops.CONV_POLICY = "auto"
+    try:
+        cases = []
+        for B, Cin, H, W, Cout, k in shapes:
+            x = _nhwc(torch.randn(B, Cin, H, W, generator=g), torch.bfloat16)
+            pw = ops.pack_conv(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), torch.randn(Cout, generator=g), torch.bfloat16, _dev())
+            ops.CONV_TUNING = 0
+            first = ops.conv2d(x, pw, emit_stats=False)
+            ops.CONV_TUNING = 1024
+            fenced = ops.conv2d(x, pw, emit_stats=False)
+            ops.CONV_TUNING = 2048
+            unsplit = ops.conv2d(x, pw, emit_stats=False)
+            ops.CONV_TUNING = 0
+            torch.cuda.synchronize()
+            assert torch.equal(first, fenced), f"{Cin}->{Cout}@{H} k{k}: unfenced hand-off differs from the release/acquire variant"
+            err = (first.float() - unsplit.float()).abs().max().item() / unsplit.float().abs().max().item()
+            assert err <= 1.6e-2, f"{Cin}->{Cout}@{H} k{k}: split vs un-split {err:.3e}"          # one bf16 ulp of the output + order
+            cases.append((x, pw, first))
+        ops.CONV_DEBUG = 1                           # every split launch first verifies that the arrival counters are zero
+        ops.conv2d(cases[0][0], cases[0][1], emit_stats=False)
+        ops.CONV_DEBUG = 0
+        side = torch.cuda.Stream()
+        hog_a = torch.empty(128 << 20, device=_dev(), dtype=torch.float32)
+        hog_b = torch.empty_like(hog_a)
+        bad = torch.zeros((), device=_dev(), dtype=torch.int32)
+        n = 0
+        for rnd in range(334):
+            if rnd % 2 == 0:
+                with torch.cuda.stream(side):        # uneven load: 1 GiB of copies in flight beside the next six launches
+                    hog_b.copy_(hog_a)
+            for x, pw, first in cases:
+                got = ops.conv2d(x, pw, emit_stats=False)
+                bad += (got != first).any().to(torch.int32)
+                n += 1
+        torch.cuda.synchronize()
+        assert n >= 2000 and int(bad.item()) == 0, f"{int(bad.item())} of {n} split-K launches differ from the first result of their shape"
+        ws = [t for t in ops._conv_ws.values() if t.device == _dev()]
+        assert ws and all(int(t[:1024].view(torch.int32).abs().max().item()) == 0 for t in ws), "arrival counters not left zero"
+    finally:
+        ops.CONV_POLICY, ops.CONV_TUNING, ops.CONV_DEBUG = old_p, old_t, old_d
+
+
+def test_poisoned_split_k_workspace_is_detected_and_replaced():
+    """nlc_conv_desc.debug bit 0: a non-zero arrival counter on entry (an aborted launch, a foreign writer) makes nlc_conv2d return
+    NLC_EINVAL instead of silently reducing early / never; ops.conv2d then drops the workspace, so the next call gets a zeroed one."""
+    from diffusion_nlc_amd import _ext, ops
+    g = torch.Generator().manual_seed(78)
+    x = _nhwc(torch.randn(16, 1024, 8, 8, generator=g), torch.bfloat16)
+    pw = ops.pack_conv(torch.randn(1024, 1024, 3, 3, generator=g) / 96, None, torch.bfloat16, _dev())
+    old_p, old_d = ops.CONV_POLICY, ops.CONV_DEBUG
+    ops.CONV_POLICY = "auto"
+    try:
+        good = ops.conv2d(x, pw)
+        torch.cuda.synchronize()
+        ws = [t for t in ops._conv_ws.values() if t.device == _dev()]
+        assert ws
+        for t in ws:
+            t[:1024].view(torch.int32)[5] = 1      # poison counter 5
+        ops.CONV_DEBUG = 1
+        with pytest.raises(_ext.NlcError, match="arrival counter 5"):
+            ops.conv2d(x, pw)
+        assert not ops._conv_ws, "the poisoned workspace must be dropped"
+        again = ops.conv2d(x, pw)                   # fresh zeroed workspace
+        torch.cuda.synchronize()
+        assert torch.equal(again, good)
+    finally:
+        ops.CONV_POLICY, ops.CONV_DEBUG = old_p, old_d
+
+
 @pytest.mark.parametrize("cout,nchw,B,H,W,Cin,scale", [(6, True, 2, 64, 128, 128, 1.0), (3, False, 4, 64, 64, 64, 0.5), (16, False, 16, 32, 32, 192, 1.0),
                                                        (1, True, 16, 32, 32, 64, 1.0), (6, True, 16, 256, 256, 256, 1.0)])    # >= 64 patches each
-def test_conv2d_narrow_output_kernel(cout, nchw, B, H, W, Cin, scale):
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+def test_conv2d_narrow_output_kernel(cout, nchw, B, H, W, Cin, scale, t16):
     """conv_narrow_kernel: 3x3 with <= 16 output channels under the production dispatch (the networks' last layer, 256 -> 6 / 128 -> 3):
     whole halo + all nine taps' weights per channel block in LDS, one barrier per block."""
     from diffusion_nlc_amd import ops
@@ -688,14 +836,14 @@ def test_conv2d_narrow_output_kernel(cout, nchw, B, H, W, Cin, scale):
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
     b = torch.randn(cout, generator=g) * 0.1
-    ref = F.conv2d(_rt(x, torch.bfloat16), _rt(w, torch.bfloat16), b, padding=1) * scale
+    ref = F.conv2d(_rt(x, t16), _rt(w, t16), b, padding=1) * scale
     old = ops.CONV_POLICY
     ops.CONV_POLICY = "auto"
     try:
-        pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
-        got = ops.conv2d(_nhwc(x, torch.bfloat16), pw, out_nchw_f32=nchw, out_scale=scale)
+        pw = ops.pack_conv(w, b, t16, _dev())
+        got = ops.conv2d(_nhwc(x, t16), pw, out_nchw_f32=nchw, out_scale=scale)
         ops.CONV_TUNING = 512                        # the same launch through the kernels that took it before
-        other = ops.conv2d(_nhwc(x, torch.bfloat16), pw, out_nchw_f32=nchw, out_scale=scale)
+        other = ops.conv2d(_nhwc(x, t16), pw, out_nchw_f32=nchw, out_scale=scale)
         torch.cuda.synchronize()
     finally:
         ops.CONV_POLICY = old
@@ -739,6 +887,8 @@ RESUPS_CASES = [
 def test_conv2d_residual_read_nearest_2x_upsampled(case):
     """nlc_conv_desc.res_upsample2x: out = conv(x) + upsample2x(res_small) - the skip branch of an up-sampling ResBlock
     (src/unet_adm.py:186-190) read in place by every epilogue that takes a residual."""
+    if case[5] in ("wide", "tall"):
+        _need_experiments()
     from diffusion_nlc_amd import ops
     B, Cin, H, W, Cout, policy, dtype = case
     g = torch.Generator().manual_seed(43)
@@ -772,6 +922,7 @@ GNTALL_CASES = [
 def test_conv2d_tall_kernel_with_groupnorm_prologue(case):
     """conv_tall_kernel<.., GN>: conv(act(a[b][c] x + b[b][c])) with the affine map (+SiLU) applied to the halo rows in LDS, once per
     patch for all 256 output channels - against F.conv2d of the explicitly normalised input (zero padding AFTER the normalisation)."""
+    _need_experiments()
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(79)
     B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
@@ -830,6 +981,7 @@ TALL_CASES = [
 def test_conv2d_tall_kernel(case):
     """conv_tall_kernel (256-pixel x 256-channel tiles, 32-channel k-blocks, ring of four weight fragments) forced for shapes of
     every kind it takes, against F.conv2d; plus its ride-along statistics."""
+    _need_experiments()
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(37)
     B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
@@ -883,6 +1035,7 @@ WIDE_CASES = [
 def test_conv2d_wide_kernel(case):
     """conv_wide_kernel (512-pixel x 128-channel tiles, one wave per SIMD, 32-channel k-blocks, buffer-load halo DMA with
     out-of-range zero fill) forced for shapes of every kind it takes, against F.conv2d; plus its ride-along statistics."""
+    _need_experiments()
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(31)
     B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
