@@ -241,20 +241,36 @@ class EDMImageExperiment(ImageExperiment):
     def evaluate_edm(self, n_samples, images_dir=None, gen=None, style="base,base", norm_eps="000", refine_prior_sigma=False,
                      microbatch=-1, sigma_scheduler="EDM", eps_ratio=0.5, eps_scale=1.0, use_second_order=True, save_fn=None):
         """:922-961: per-batch host generators seeded 0..n-1 (StackedRandomGenerator), samples mapped to [0,1].
-        PNG writing / FID are optional side effects: ``save_fn(sample01, batch_index)`` if given."""
+        PNG writing / FID are optional side effects: ``save_fn(sample01, batch_index)`` if given.
+
+        Under a launcher (one process per GPU, shard.init_from_env) rank r samples batches r, r+W, ...: every sample owns its
+        generator (seed = global sample index), so nothing has to be replayed; one all-gather collects the samples in order on
+        every rank, and rank 0 runs ``save_fn`` / FID."""
+        from . import shard
+        world, rank = shard.world_rank()
         batch_size = microbatch if microbatch > 0 else self.batch_size
         if n_samples % batch_size:
             raise ValueError("n_samples must be a multiple of batch_size (the reference asserts this at :77, SURVEY.md §9)")
         seeds = torch.arange(n_samples).tensor_split(n_samples // batch_size)
         outs = []
         for i, sd in enumerate(seeds):
+            if i % world != rank:
+                continue
             g = StackedRandomGenerator(self.device, sd)
             x = self.edm_sampler(shape=(batch_size,) + self.data_shape, gen=g, style=style, norm_eps=norm_eps,
                                  refine_prior_sigma=refine_prior_sigma, sigma_scheduler=sigma_scheduler, eps_ratio=eps_ratio,
                                  eps_scale=eps_scale, use_second_order=use_second_order)
             sample = x.add(1).div(2).clamp(0, 1)
-            if save_fn is not None:
+            if save_fn is not None and world == 1:
                 save_fn(sample, i)
             outs.append(sample)
-        fid = self.fid_fn(images_dir) if (self.fid_fn is not None and images_dir) else float("nan")
+        if world > 1:
+            local = torch.stack(outs) if outs else torch.empty((0, batch_size) + tuple(self.data_shape), device=self.device, dtype=torch.float64)
+            allx = shard.gather_samples(local, len(seeds), world, rank)
+            if save_fn is not None and rank == 0:
+                for i in range(len(seeds)):
+                    save_fn(allx[i], i)
+            shard.barrier()
+            outs = list(allx)
+        fid = self.fid_fn(images_dir) if (self.fid_fn is not None and images_dir and rank == 0) else float("nan")
         return {"fid": fid}, torch.cat(outs)

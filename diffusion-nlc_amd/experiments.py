@@ -128,6 +128,20 @@ class ExperimentDiffusion:
     def new_gen(self, seed=None):
         return torch.manual_seed(self.seed if seed is None else seed)
 
+    def host_draws_per_batch(self, new_eta=None) -> int:
+        """How many ``randn(batch_shape)`` one ``denoise_loop`` batch takes from the host generator: the initial state plus, for
+        stochastic samplers, one per timestep (``new_eta`` switches the last step, src/experiments.py:349-350).  A sharded run
+        replays this many draws for every batch another rank owns (shard.replay_draws) so that the single generator of
+        image_sample.py:529 stays in step with the single-process run."""
+        S = self.scheduler
+        n = 1
+        steps = len(S.timesteps) - 1
+        for ind in range(steps):
+            eta = new_eta if (ind == S.num_inference_steps - 1 and new_eta is not None) else S.eta
+            if eta > 0 or S.variant in ("ddpm", "ddpm_orig"):
+                n += 1
+        return n
+
     @ops.on_device
     def get_noise(self, shape=None, gen=None, norm_noise=False):
         noise = torch.randn(self.shape if shape is None else shape, generator=self.gen if gen is None else gen)

@@ -49,6 +49,34 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+def world_rank() -> tuple:
+    """(world, rank) of the running job: the initialised process group if there is one, else a single process."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def broadcast_object(obj, src: int = 0):
+    """Small host object from rank ``src`` to every rank (directory names, the skip-if-exists decisions)."""
+    world, _ = world_rank()
+    if world == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def barrier() -> None:
+    if world_rank()[0] > 1:
+        dist.barrier()
+
+
+def replay_draws(gen: torch.Generator, shape: Sequence[int], n: int) -> None:
+    """Advance the reference's single host generator past a batch another rank samples: ``n`` x randn(shape), discarded."""
+    for _ in range(n):
+        torch.randn(tuple(shape), generator=gen)
+
+
 def gather_samples(local: torch.Tensor, n_batches: int, world: int, rank: int) -> torch.Tensor:
     """All-gather per-rank results [n_local, B, ...] and restore global batch order -> [n_batches, B, ...].
 

@@ -75,6 +75,11 @@ def get_args(argv=None):
 
 
 def main(args):
+    # one process per GPU under a launcher: join before anything touches a device, rank r drives cuda:LOCAL_RANK
+    from diffusion_nlc_amd import shard
+    rank, world, local = shard.init_from_env()
+    if world > 1 and torch.device(args.device).type == "cuda":
+        args.device = f"cuda:{local}"
     if args.synthetic:
         cfg = dict(SYNTHETIC[args.synthetic])
         saved = dict(sigma_block=2, sigma_dropout=0.0)
@@ -119,6 +124,9 @@ def main(args):
                                          use_second_order=bool(args.use_second_order))
     print(log_dict, tuple(samples.shape))
     print("evaluate done")
+    if world > 1:
+        shard.barrier()
+        torch.distributed.destroy_process_group()
     return log_dict, samples
 
 

@@ -219,17 +219,35 @@ def save_png(img, path):
 def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=False, style="base", sampling="denoise",
                           norm_eps=False, refine_prior_sigma=False, sigma_estimate_rate=(1, 0, 0, 0), max_T=None,
                           sigma_pred_threshold=1000, new_eta=None, recal_sigma_prev=False, return_log=False, save_images=True):
-    """image_sample.py:522-569: ceil(n/B) full batches from ONE host generator, skip batches whose PNGs exist."""
+    """image_sample.py:522-569: ceil(n/B) full batches from ONE host generator, skip batches whose PNGs exist.
+
+    Under a launcher (``torchrun --nproc-per-node N image_sample.py ...``, one process per GPU; BASELINE config 5) the batches
+    that are to be sampled are dealt round-robin over the ranks.  Every rank walks the WHOLE batch list with the reference's
+    single host generator: it samples its own batches and, for a batch another rank owns, draws and discards exactly what that
+    batch takes from the generator (initial state + per-step noise of stochastic samplers), so each sample equals the
+    single-process run's.  The skip-if-exists decisions (which do not advance the generator upstream either) are taken once, by
+    rank 0, before anything is written.  One all-gather (RCCL over xGMI) collects the finished samples; rank 0 writes the PNGs
+    and computes FID.  ``return_log`` lists are per rank (rank 0 returns those of its own batches)."""
+    from diffusion_nlc_amd import shard
+    world, rank = shard.world_rank()
     B = experiment.batch_size
-    shape = (B,) + experiment.data_shape
+    shape = (B,) + tuple(experiment.data_shape)
     gen = experiment.new_gen()
-    logs = []
-    for i in range(math.ceil(n_samples / B)):
-        paths = [os.path.join(images_dir, f"00-{i:05}-{j:03}.png") for j in range(B)]
-        if save_images and all(os.path.exists(p) for p in paths):
-            print("skip images for:", f"00-{i:05}-(000~{B - 1:03}).png")
+    n_batches = math.ceil(n_samples / B)
+    all_paths = [[os.path.join(images_dir, f"00-{i:05}-{j:03}.png") for j in range(B)] for i in range(n_batches)]
+    skip = [bool(save_images and all(os.path.exists(p) for p in paths)) for paths in all_paths]
+    skip = shard.broadcast_object(skip)                          # one decision for every rank, taken before any rank writes
+    todo = [i for i in range(n_batches) if not skip[i]]
+    if world > 1 and sampling == "project" and experiment.host_draws_per_batch(new_eta) != 1:
+        raise NotImplementedError("sharded --sampling project needs a deterministic sampler (the projection loop's step count, and so "
+                                  "its number of host noise draws, is data dependent)")
+    logs, mine = [], []
+    for k, i in enumerate(todo):
+        if k % world != rank:
+            shard.replay_draws(gen, shape, experiment.host_draws_per_batch(new_eta))
             continue
         t1 = time()
+        extra = dict(return_on_device=True) if world > 1 else {}
         if sampling == "project":
             sample, return_list = projection_loop(experiment, shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
                                                   constrain_fn=None, norm_eps=norm_eps, refine_prior_sigma=refine_prior_sigma,
@@ -241,15 +259,30 @@ def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=Fal
             sample, return_list = experiment.denoise_loop(shape=shape, gen=gen, norm_init_noise=norm_init_noise, style=style,
                                                           constrain_fn=None, norm_eps=norm_eps,
                                                           refine_prior_sigma=refine_prior_sigma, return_log=return_log,
-                                                          chunk_size=1, sigma_pred_threshold=sigma_pred_threshold, new_eta=new_eta)
+                                                          chunk_size=1, sigma_pred_threshold=sigma_pred_threshold, new_eta=new_eta,
+                                                          **extra)
         print("time:", time() - t1)
         logs.append(return_list)
         sample = sample.add(1).div(2).clamp(0, 1)
-        if save_images:
-            for img, p in zip(sample, paths):
-                save_png(img, p)
-        print(f"done batches:{i}/{math.ceil(n_samples / B)}")
-    fid = experiment.fid_fn(images_dir) if experiment.fid_fn is not None else float("nan")
+        if world == 1:
+            if save_images:
+                for img, p in zip(sample, all_paths[i]):
+                    save_png(img, p)
+        else:
+            mine.append(sample)
+        print(f"done batches:{i}/{n_batches}")
+    if world > 1:
+        dev = getattr(experiment, "device", "cpu")
+        local = torch.stack(mine) if mine else torch.empty((0,) + shape, device=dev)
+        allx = shard.gather_samples(local.to(dev), len(todo), world, rank)        # [len(todo), B, C, H, W] in batch order, every rank
+        if rank == 0 and save_images:
+            for k, i in enumerate(todo):
+                for img, p in zip(allx[k], all_paths[i]):
+                    save_png(img, p)
+        shard.barrier()                                          # the PNGs are on disk before anyone computes FID / returns
+    fid = float("nan")
+    if rank == 0 and experiment.fid_fn is not None:
+        fid = experiment.fid_fn(images_dir)
     return {"fid": fid}, logs
 
 
@@ -347,16 +380,24 @@ def evaluate_constraint(experiment, data_loader, Constraint, images_dir, n_sampl
 
 
 def main(args, config):
+    # One process per GPU under a launcher (RANK / WORLD_SIZE / LOCAL_RANK in the environment; INTEGRATION.md shows the torchrun
+    # line): joined BEFORE anything touches a device; rank r drives cuda:LOCAL_RANK.  Rank 0 owns the output directory.
+    from diffusion_nlc_amd import shard
+    rank, world, local = shard.init_from_env()
+    if world > 1 and torch.device(args.device).type == "cuda":
+        args.device = f"cuda:{local}"
     if args.save_folder is not None:
         args.test_dir = args.save_folder
     else:
         i = 0
         while os.path.exists(os.path.join(args.test_dir, str(i))):
             i += 1
-        args.test_dir = os.path.join(args.test_dir, str(i))
-    os.makedirs(args.test_dir, exist_ok=True)
-    with open(os.path.join(args.test_dir, "args.json"), "w") as f:
-        json.dump({k: (str(v) if k == "device" else v) for k, v in vars(args).items()}, f)
+        args.test_dir = shard.broadcast_object(os.path.join(args.test_dir, str(i)))      # every rank uses rank 0's choice
+    if rank == 0:
+        os.makedirs(args.test_dir, exist_ok=True)
+        with open(os.path.join(args.test_dir, "args.json"), "w") as f:
+            json.dump({k: (str(v) if k == "device" else v) for k, v in vars(args).items()}, f)
+    shard.barrier()
     if args.seed is not None:
         random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
 
@@ -408,9 +449,14 @@ def main(args, config):
     experiment.set_clip_fn(args.clip_fn)
 
     images_dir = os.path.join(args.test_dir, args.save_flag, "images")
-    if os.path.exists(images_dir) and args.sample_overwrite:
-        shutil.rmtree(images_dir)
-    os.makedirs(images_dir, exist_ok=True)
+    if rank == 0:
+        if os.path.exists(images_dir) and args.sample_overwrite:
+            shutil.rmtree(images_dir)
+        os.makedirs(images_dir, exist_ok=True)
+    shard.barrier()
+    if args.constraint != "none" and world > 1:
+        raise NotImplementedError("constrained runs select the best x0 by a BATCH-mean loss and read a data loader in order: they are not "
+                                  "sharded (SURVEY.md §8e); run them as one process per job")
     if args.constraint == "none":
         log_dict, return_lists = evaluate_unconstraint(
             experiment, args.sample_size, images_dir, norm_init_noise=args.norm_init_noise, style=args.sigma_type,
@@ -418,7 +464,7 @@ def main(args, config):
             sigma_estimate_rate=args.sigma_estimate_rate, max_T=args.max_T, sigma_pred_threshold=args.sigma_pred_threshold,
             new_eta=args.new_eta, recal_sigma_prev=args.recal_sigma_prev, return_log=bool(args.return_log),
             save_images=bool(args.save_png))
-        if args.return_log:
+        if args.return_log and rank == 0:
             torch.save(return_lists, os.path.join(args.test_dir, args.save_flag, "results_dump.pt"))
     else:
         if not args.synthetic:
@@ -432,11 +478,15 @@ def main(args, config):
             prior_xt=args.prior_xt, sigma_estimate_rate=args.sigma_estimate_rate, return_log=False, max_T=args.max_T,
             sigma_pred_threshold=args.sigma_pred_threshold, new_eta=args.new_eta, recal_sigma_prev=args.recal_sigma_prev,
             save_images=bool(args.save_png))
-    with open(os.path.join(args.test_dir, args.save_flag, "results.json"), "w") as f:
-        json.dump(log_dict, f)
+    if rank == 0:
+        with open(os.path.join(args.test_dir, args.save_flag, "results.json"), "w") as f:
+            json.dump(log_dict, f)
     log_dict.pop("full_log", None)
     print(log_dict)
     print("evaluate done")
+    if world > 1:
+        shard.barrier()
+        torch.distributed.destroy_process_group()
     return log_dict
 
 
