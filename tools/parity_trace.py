@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--timesteps", type=int, default=50)
     ap.add_argument("--precisions", nargs="+", default=["bf16", "f16", "f32x3", "f32"])
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "parity_trace.json"))
+    ap.add_argument("--conditioning", action="store_true",
+                    help="also run the ORACLE itself a second time from x_T perturbed by one f32 ulp per element (random sign): how far two "
+                         "runs of the reference arithmetic drift apart over the same timesteps - the floor for ANY independent implementation")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ns = argparse.Namespace(tiny=False, batch=1, timesteps=50, dry_run=False, dtype="f32")
@@ -46,18 +49,31 @@ def main():
                         clip_fn="dynamic")
     z = torch.randn((1, 3, 256, 256), generator=torch.Generator().manual_seed(1234))
     xT = z / (1 / (s.sampling_sigmas[0] ** 2 + 1)).sqrt()
-    xt, x0_ref, sig_ref = xT, [], []
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        for n in range(args.timesteps):
-            eps, lv, st, sp = o.get_denoise_vector(xt, s.timesteps[n], s.sampling_sigmas[n], s.sampling_sigmas[n + 1], "pred", True, True)
-            x0 = o.clip(s.pred_xstart(xt, eps, st))
-            x0_ref.append(x0.clone()); sig_ref.append(st.reshape(-1).clone())
-            xt = s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=xt, log_variance=lv)
-            if n % 5 == 4:
-                print(f"oracle: {n + 1} timesteps, {time.perf_counter() - t0:.0f} s", flush=True)
+    def oracle_run(x_start, tag):
+        xt, x0s, sigs = x_start, [], []
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for n in range(args.timesteps):
+                eps, lv, st, sp = o.get_denoise_vector(xt, s.timesteps[n], s.sampling_sigmas[n], s.sampling_sigmas[n + 1], "pred", True, True)
+                x0 = o.clip(s.pred_xstart(xt, eps, st))
+                x0s.append(x0.clone()); sigs.append(st.reshape(-1).clone())
+                xt = s.pred_xprev(x0=x0, eps=eps, sigma_t=st, sigma_prev=sp, xt=xt, log_variance=lv)
+                if n % 5 == 4:
+                    print(f"{tag}: {n + 1} timesteps, {time.perf_counter() - t0:.0f} s", flush=True)
+        return x0s, sigs, time.perf_counter() - t0
+
+    x0_ref, sig_ref, secs = oracle_run(xT, "oracle")
     out = {"model": "ADM-256 (filler weights), DDIM+NLC 50-step schedule, B=1, seed 1234", "timesteps": args.timesteps,
-           "oracle_seconds": time.perf_counter() - t0, "x0_rms_final": float(x0_ref[-1].double().pow(2).mean().sqrt()), "precisions": {}}
+           "oracle_seconds": secs, "x0_rms_final": float(x0_ref[-1].double().pow(2).mean().sqrt()), "precisions": {}}
+    if args.conditioning:
+        sign = torch.randint(0, 2, xT.shape, generator=torch.Generator().manual_seed(1)).float() * 2 - 1
+        xT2 = (xT * (1 + sign * 2.0 ** -23)).float()              # one ulp per element, random sign
+        x0_b, sig_b, _ = oracle_run(xT2, "oracle (x_T perturbed by 1 ulp)")
+        linf = [float((x0_b[i].double() - x0_ref[i].double()).abs().max()) for i in range(args.timesteps)]
+        rms = [float((x0_b[i].double() - x0_ref[i].double()).pow(2).mean().sqrt()) for i in range(args.timesteps)]
+        out["oracle_vs_oracle_1ulp"] = {"x0_linf_per_timestep": linf, "x0_rms_per_timestep": rms, "final_linf": linf[-1], "max_linf": max(linf),
+                                        "what": "the CPU oracle (the reference's arithmetic) against itself, x_T perturbed by one f32 ulp per element"}
+        print(f"oracle vs oracle (1 ulp): x0 L-inf first {linf[0]:.3e}  max {max(linf):.3e}  final {linf[-1]:.3e}  RMS final {rms[-1]:.3e}", flush=True)
     for name in args.precisions:
         for m in (wl.exp.model, wl.exp.sigma_model):
             bench.set_precision(m, bench.PRECISIONS[name])
