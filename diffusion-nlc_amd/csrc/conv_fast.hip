@@ -58,9 +58,11 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 
 template <int N> __device__ __forceinline__ void dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// STAGES = 2 (the only instantiation shipped): two workgroups per CU hide each other's DMA latency.  STAGES = 3 / 4 - one workgroup
-// per CU with the DMA of 2 / 3 k-steps in flight behind a counted wait - were measured on every shape of tools/conv_bench.py and
-// are slower everywhere, by 10-45 % (profiles/r02_summary.md): eight resident waves matter more than the deeper pipeline.
+// STAGES = 2: two workgroups per CU hide each other's DMA latency - the choice wherever a launch has more workgroups than CUs
+// (STAGES = 3 / 4 measured 10-45 % slower on every such shape of tools/conv_bench.py, profiles/r02_summary.md: eight resident waves
+// matter more than a deeper pipeline).  STAGES = 4: launches with AT MOST one workgroup per CU (the 8x8 ... 32x32 levels at small
+// batch: 16-256 workgroups) have nobody to overlap with, and with one k-step in flight every k-step pays a whole memory latency
+// (measured 2.3 us per k-step, 42 us for 18 k-steps of 512 -> 512 @8x8, B = 8); three k-steps in flight behind a counted wait.
 // X3 (T = float, NLC_MATH_F16X3): f32 tensors, split-f16 matrix math (conv_halo.hip has the scheme).  The weights arrive packed as
 // (hi, lo) halves, so the two weight reads of a k-step ARE the two operand halves; the activation tile is staged once per tap here
 // and read by two waves only, so its fragments are split in registers (conv_params.h: f16x3_split4), 64 VALU per 48 MFMAs.
@@ -529,8 +531,9 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     const bool k3 = p.KH == 3;
     const int tiles = p.MT * p.NT;
     const int ncb = p.Cin_pad / (nlc_is16(dtype) ? Mma<bf16_raw>::KBE : Mma<float>::KBE);
-    if (tiles >= 512) return 1;
-    int s = cdiv(512, tiles);
+    const int target = (p.tuning & 16384) ? 256 : 512;           // workgroups aimed at (A/B: bit 14 = one per CU)
+    if (tiles >= target) return 1;
+    int s = cdiv(target, tiles);
     const int min_cb = k3 ? 2 : 8;                   // >= 18 (3x3) / 8 (1x1) k-steps per split
     if (s > ncb / min_cb) s = ncb / min_cb;
     if (s > 8) s = 8;
@@ -556,6 +559,15 @@ int64_t nlc_conv_fast_split_bytes(const KParams& p, int ks) {
 int nlc_conv_fast_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!fast_shape(p)) return NLC_EUNSUPPORTED;
     const bool k3 = p.KH == 3;
+    // deep pipeline for launches that leave every workgroup alone on its CU (tuning bit 12: never, bit 13: always - A/B)
+    static DeviceOnce once;
+    const int ncu = once.ncu[nlc_device_once(once, [] {})];
+    const int64_t grid = (int64_t)p.MT * p.NT * p.ksplit;
+    const bool deep = (p.tuning & 8192) ? true : (p.tuning & 4096) ? false : grid <= ncu;
+    if (deep && nlc_is16(dtype)) {
+        if (dtype == NLC_BF16) return k3 ? launch_fast<bf16_raw, 9, 4>(p, stream) : launch_fast<bf16_raw, 1, 4>(p, stream);
+        return k3 ? launch_fast<f16_raw, 9, 4>(p, stream) : launch_fast<f16_raw, 1, 4>(p, stream);
+    }
     if (dtype == NLC_BF16) return k3 ? launch_fast<bf16_raw, 9, 2>(p, stream) : launch_fast<bf16_raw, 1, 2>(p, stream);
     if (dtype == NLC_F16) return k3 ? launch_fast<f16_raw, 9, 2>(p, stream) : launch_fast<f16_raw, 1, 2>(p, stream);
     if (p.math == NLC_MATH_F16X3) return k3 ? launch_fast<float, 9, 2, true>(p, stream) : launch_fast<float, 1, 2, true>(p, stream);

@@ -37,8 +37,25 @@ SHAPES = [  # (H, Cin, Cout, k, note); a trailing "ups" in the note = fused near
 ]
 
 
+# the small-map launches of cfg 4 (CelebA-HQ-256 simple UNet, use --batch 8) and of ADM-256's 8x8 / 16x16 levels: few tiles, long K
+SMALL = [
+    (8, 512, 512, 3, "512->512 @8^2"),
+    (8, 1024, 512, 3, "1024->512 @8^2"),
+    (16, 512, 512, 3, "512->512 @16^2"),
+    (16, 1024, 512, 3, "1024->512 @16^2"),
+    (32, 256, 256, 3, "256->256 @32^2"),
+    (32, 512, 256, 3, "512->256 @32^2"),
+    (16, 512, 1536, 1, "qkv 512->1536 @16^2"),
+    (16, 512, 512, 1, "proj 512->512 @16^2"),
+    (8, 1024, 512, 1, "nin 1024->512 @8^2"),
+    (8, 1024, 1024, 3, "1024->1024 @8^2"),
+    (8, 2048, 1024, 3, "2048->1024 @8^2"),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--set", default="adm", choices=["adm", "small"], help="shape list: the ADM-256 hot shapes, or the small-map launches")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
@@ -52,6 +69,8 @@ def main():
                     "(what the clock does to the rate: MI355X_MICROARCH.md 'DVFS give-back')")
     args = ap.parse_args()
     global SHAPES
+    if args.set == "small":
+        SHAPES = SMALL
     if args.only >= 0:
         SHAPES = SHAPES[args.only:args.only + 1]
     elif args.first:
