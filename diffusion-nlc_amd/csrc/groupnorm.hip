@@ -299,54 +299,72 @@ struct GNCoefOut {        // optional second product of gn_finalize_chunks_kerne
     float* coef;          // [B][C][2] or NULL
     const float* gamma; const float* beta; const float* scale; const float* shift; int ss_stride;
 };
+// TPG threads per group (a power of two, 8 ... 256, chosen by the host from the amount of work per group), NT / TPG groups per
+// workgroup: with one workgroup per (group, image) a batch of 200 32x32 maps launched 6400 workgroups of 256 threads for 16 loads
+// each (10 us per launch, 6 % of an EDM network evaluation).  Fixed summation order: thread l of a group takes items l, l + TPG, ...
+// of the (chunk, partial) list, then a tree over the group's threads.
 __global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __restrict__ s0, int P0, int C0,
                                                               const float* __restrict__ s1, int P1, int C1,
                                                               int gs, int G, int HW, float eps, float* __restrict__ stat,
-                                                              const GNCoefOut co) {
+                                                              const GNCoefOut co, int TPG) {
     __shared__ double red[2][NT];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int q0 = g * gs / 8, q1 = (g + 1) * gs / 8;           // chunk range of this group over cat(x0, x1)
+    __shared__ float s_mean[NT / 8], s_rstd[NT / 8];
+    const int gpw = NT / TPG;                                  // groups per workgroup
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int gl = tid / TPG, l = tid - gl * TPG;
+    const int g = blockIdx.x * gpw + gl;
     const int nq0 = C0 / 8, nq1 = C1 / 8;
     double a = 0.0, c = 0.0;
-    for (int q = q0; q < q1; ++q) {
-        const bool second = q >= nq0;
-        const float* src = second ? s1 : s0;
-        const int P = second ? P1 : P0, nq = second ? nq1 : nq0, qq = second ? q - nq0 : q;
-        const float* base = src + ((int64_t)b * P * nq + qq) * 2;
-        for (int pp = tid; pp < P; pp += NT) {
-            const float2 v = *reinterpret_cast<const float2*>(base + (int64_t)pp * nq * 2);
-            a += (double)v.x; c += (double)v.y;
+    if (g < G) {
+        const int q0 = g * gs / 8, q1 = (g + 1) * gs / 8;       // chunk range of this group over cat(x0, x1)
+        for (int q = q0; q < q1; ++q) {
+            const bool second = q >= nq0;
+            const float* src = second ? s1 : s0;
+            const int P = second ? P1 : P0, nq = second ? nq1 : nq0, qq = second ? q - nq0 : q;
+            const float* base = src + ((int64_t)b * P * nq + qq) * 2;
+            for (int pp = l; pp < P; pp += TPG) {
+                const float2 v = *reinterpret_cast<const float2*>(base + (int64_t)pp * nq * 2);
+                a += (double)v.x; c += (double)v.y;
+            }
         }
     }
     red[0][tid] = a; red[1][tid] = c;
     __syncthreads();
-    for (int o = NT / 2; o > 0; o >>= 1) {
-        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    for (int o = TPG / 2; o > 0; o >>= 1) {
+        if (l < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
         __syncthreads();
     }
-    const double N = (double)HW * gs;
-    const double mean_d = red[0][0] / N;
-    double var = red[1][0] / N - mean_d * mean_d;
-    if (var < 0.0) var = 0.0;
-    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
-    if (tid == 0 && stat) {
-        stat[((int64_t)b * G + g) * 2 + 0] = mean;
-        stat[((int64_t)b * G + g) * 2 + 1] = rstd;
+    if (l == 0 && g < G) {
+        const double N = (double)HW * gs;
+        const double mean_d = red[0][tid] / N;
+        double var = red[1][tid] / N - mean_d * mean_d;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+        s_mean[gl] = mean; s_rstd[gl] = rstd;
+        if (stat) {
+            stat[((int64_t)b * G + g) * 2 + 0] = mean;
+            stat[((int64_t)b * G + g) * 2 + 1] = rstd;
+        }
     }
     if (co.coef) {
-        // the same a / b factorisation gn_apply_fast_kernel evaluates per thread, written once per (image, channel) for the
-        // convolution that applies the normalisation in its LDS prologue (nlc_conv_desc.gn_coef)
+        // the same a / b factorisation gn_apply_fast_kernel evaluates per thread, written once per (image, channel): for the apply
+        // kernel (four 16-byte loads instead of the per-channel algebra) and for a convolution that applies the normalisation in
+        // its LDS prologue (nlc_conv_desc.gn_coef)
+        __syncthreads();
         const int C = C0 + C1;
-        for (int j = tid; j < gs; j += NT) {
-            const int c = g * gs + j;
-            float a = rstd * (co.gamma ? co.gamma[c] : 1.f);
-            float bb = (co.beta ? co.beta[c] : 0.f) - mean * a;
+        const int g0 = blockIdx.x * gpw, ng = min(gpw, G - g0);
+        for (int j = tid; j < ng * gs; j += NT) {
+            const int gi = j / gs;
+            const int ch = g0 * gs + j;
+            const float mean = s_mean[gi], rstd = s_rstd[gi];
+            float aa = rstd * (co.gamma ? co.gamma[ch] : 1.f);
+            float bb = (co.beta ? co.beta[ch] : 0.f) - mean * aa;
             if (co.scale) {
-                const float sc = 1.f + co.scale[(int64_t)b * co.ss_stride + c];
-                const float sh = co.shift[(int64_t)b * co.ss_stride + c];
-                a *= sc; bb = bb * sc + sh;
+                const float sc = 1.f + co.scale[(int64_t)b * co.ss_stride + ch];
+                const float sh = co.shift[(int64_t)b * co.ss_stride + ch];
+                aa *= sc; bb = bb * sc + sh;
             }
-            *reinterpret_cast<float2*>(co.coef + ((int64_t)b * C + c) * 2) = float2{a, bb};
+            *reinterpret_cast<float2*>(co.coef + ((int64_t)b * C + ch) * 2) = float2{aa, bb};
         }
     }
 }
@@ -536,6 +554,16 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
         else { using TG = float; __VA_ARGS__; }                          \
     } while (0)
 
+// threads per group of gn_finalize_chunks_kernel: ~16 (chunk, partial) items per thread, a power of two in [8, 256]
+static int finalize_tpg(int gs, int P0, int P1, int C0, int C1) {
+    const int64_t items = (int64_t)(gs / 8 > 0 ? gs / 8 : 1) * (P0 > P1 ? P0 : P1);
+    (void)C0; (void)C1;
+    int tpg = 8;
+    while (tpg < NT && (int64_t)tpg * 16 < items) tpg *= 2;
+    return tpg;
+}
+#define FIN_GRID(G, B, tpg) dim3(cdiv((G), NT / (tpg)), (B))
+
 // Pixels per apply workgroup: `unit` (= ps x unroll x 4 trips) for the big maps, capped so the grid stays <= GN_APPLY_MAXBLK
 // workgroups; halved down to `ps` (one chunk per thread) while the launch would have fewer than 512 workgroups - the 8x8 ... 32x32
 // levels otherwise ran 16 ... 128 workgroups of four dependent trips each on a 256-CU chip (12-15 us per launch instead of ~5).
@@ -628,8 +656,9 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     // the finalize kernel also folds gamma / beta / FiLM into one (a, b) pair per (image, channel): the apply threads then start
     // with four 16-byte loads instead of five scalar loads and the algebra per channel
     float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
-    hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
-                       eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride});
+    const int tpg = finalize_tpg(p.gs, P0, P1, C0, C1);
+    hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
+                       eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg);
 #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
     p.coef = coef;
 #endif
@@ -661,8 +690,9 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
     float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
     if (stats0) {
         float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
-        hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
-                           groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride});
+        const int tpg = finalize_tpg(p.gs, P0, 0, C, 0);
+        hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
+                           groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg);
     #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
     p.coef = coef;
 #endif
@@ -692,8 +722,9 @@ extern "C" int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, flo
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_coef: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_coef: ss_stride < C");
     GNCoefOut co{coef, gamma, beta, scale, shift, ss_stride};
-    hipLaunchKernelGGL(gn_finalize_chunks_kernel, dim3(groups, B), dim3(NT), 0, (hipStream_t)stream, stats0, P0, C0, stats1, P1, C1,
-                       C / groups, groups, HW, eps, (float*)nullptr, co);
+    const int tpg = finalize_tpg(C / groups, P0, P1, C0, C1);
+    hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, (hipStream_t)stream, stats0, P0, C0, stats1, P1, C1,
+                       C / groups, groups, HW, eps, (float*)nullptr, co, tpg);
     NLC_CHECK_LAUNCH("nlc_groupnorm_coef");
     return NLC_OK;
 }
