@@ -226,6 +226,10 @@ class ExperimentDiffusion:
             if self.sigma_model is None:
                 raise NlcError("style '%s' needs a sigma model (set_model)" % style)
             feat = self.model.run(xt, st["t"], mode="encode", in_scale=st["c_in"], feat_nhwc=True)
+            if feat.dtype != self.sigma_model.compute_dtype:
+                # the two networks may run in different precisions, as upstream (use_fp16 / use_sigma_fp16, image_sample.py:378-381):
+                # the small feature map goes through the reference's own f32 NCHW format
+                feat = ops.nchw_f32_to_nhwc(ops.nhwc_to_nchw_f32(feat), self.sigma_model.compute_dtype)
             r = self.sigma_model.run_nhwc(feat)
             ops.sigma_correct(r, style != "pred", S.device_sigmas(self.device), st["sigma_t"], st["sigma_prev"], st["t"],
                               st["c_in"], t_slopes=slopes)
