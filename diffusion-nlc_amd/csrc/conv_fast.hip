@@ -346,7 +346,8 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
 #pragma unroll
         for (int k = 0; k < 16; ++k) { const float vb = bp[hb ? min(n + k, last) : k]; cbias[k] = (n + k < p.Cout) ? vb : 0.f; }
     }
-    float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};            // GroupNorm statistics: two 8-channel chunks, 4 pixels
+    Stat16 st16;                                                // ride-along GroupNorm statistics: this lane's 16 channels, 4 pixels
+    st16.zero();
     bool done = false;
     if constexpr (sizeof(T) == 2) {
         // hot path (bf16, whole 16-channel slice, NHWC, no per-image embedding): option switches hoisted out of the
@@ -387,19 +388,14 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                 const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
                 *reinterpret_cast<uint4*>(op) = pk0;
                 *reinterpret_cast<uint4*>(op + 8) = pk1;
-                if (has_stats) {         // of the STORED (bf16-rounded) values - what the GroupNorm that follows reads
-                    float sv[16];
-                    chunk_to_f32<T>(pk0, sv); chunk_to_f32<T>(pk1, sv + 8);
-                    if (pix_stats) { gsum[0] = gsum[1] = gsq[0] = gsq[1] = 0.f; }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        gsum[0] += sv[k]; gsq[0] = fmaf(sv[k], sv[k], gsq[0]);
-                        gsum[1] += sv[8 + k]; gsq[1] = fmaf(sv[8 + k], sv[8 + k], gsq[1]);
-                    }
+                if (has_stats) {         // of the STORED (rounded) values - what the GroupNorm that follows reads
+                    float s0[8], s1[8];
+                    chunk_to_f32<T>(pk0, s0); chunk_to_f32<T>(pk1, s1);
+                    if (pix_stats) st16.zero();
+                    st16.add8(0, s0); st16.add8(1, s1);
                     if (pix_stats) {     // [b][pixel][chunk][{sum, sumsq}], stats_P = Hout * Wout
                         const int b = m / HWo;
-                        float* dst = p.stats + (((int64_t)b * p.stats_P + (m - b * HWo)) * (p.Cout >> 3) + (n >> 3)) * 2;
-                        *reinterpret_cast<float4*>(dst) = float4{gsum[0], gsq[0], gsum[1], gsq[1]};
+                        st16.store(p.stats, (int64_t)b * p.stats_P + (m - b * HWo), p.Cout, n, p.stats_gran);
                     }
                 }
             }
@@ -453,17 +449,13 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                         if (p.stats) {
                             float sv[8];
                             chunk_to_f32<T>(pk, sv);
-                            if (pix_stats) { gsum[c] = 0.f; gsq[c] = 0.f; }
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) { gsum[c] += sv[q]; gsq[c] = fmaf(sv[q], sv[q], gsq[c]); }
+                            if (pix_stats && c == 0) st16.zero();
+                            st16.add8(c, sv);
                         }
                     }
                 }
                 if constexpr (sizeof(T) == 2) {
-                    if (p.stats && pix_stats) {
-                        float* dst = p.stats + (((int64_t)b * p.stats_P + (m - b * HWo)) * (p.Cout >> 3) + (n >> 3)) * 2;
-                        *reinterpret_cast<float4*>(dst) = float4{gsum[0], gsq[0], gsum[1], gsq[1]};
-                    }
+                    if (p.stats && pix_stats) st16.store(p.stats, (int64_t)b * p.stats_P + (m - b * HWo), p.Cout, n, p.stats_gran);
                 }
             } else {
 #pragma unroll
@@ -486,12 +478,12 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                 x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
                 return x;
             };
-            const float r4[4] = {row16_sum(gsum[0]), row16_sum(gsq[0]), row16_sum(gsum[1]), row16_sum(gsq[1])};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
             if (fr == 0) {
                 const int b = m0 / HWo;
                 const int part = ((m0 - b * HWo) / BM) * 2 + wm;
-                float* dst = p.stats + (((int64_t)b * p.stats_P + part) * (p.Cout >> 3) + (n >> 3)) * 2;
-                *reinterpret_cast<float4*>(dst) = float4{r4[0], r4[1], r4[2], r4[3]};
+                st16.store(p.stats, (int64_t)b * p.stats_P + part, p.Cout, n, p.stats_gran);
             }
         }
     }

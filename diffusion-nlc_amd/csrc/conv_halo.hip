@@ -376,7 +376,8 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             load_cadd(nx, cnext);                    // in flight while this tile is stored
         }
         const int n = t.n0 + wn * 64 + fq * 16;
-        float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};        // this lane's two 8-channel chunks over its 4 pixels
+        Stat16 st16;                                 // this lane's 16 channels over its 4 pixels (ride-along GroupNorm statistics)
+        st16.zero();
         bool done = false;
         bool parked = false;                         // SPLIT: this workgroup was not the last to arrive at its tile - no output from it
         if constexpr (SPLIT) {                       // dispatch: bf16, Cout % 128 == 0
@@ -499,14 +500,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
                     *reinterpret_cast<uint4*>(op) = pk0;
                     *reinterpret_cast<uint4*>(op + 8) = pk1;
-                    if (has_stats) {     // of the STORED (bf16-rounded) values - what the GroupNorm that follows reads
-                        float sv[16];
-                        chunk_to_f32<T>(pk0, sv); chunk_to_f32<T>(pk1, sv + 8);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            gsum[0] += sv[k]; gsq[0] = fmaf(sv[k], sv[k], gsq[0]);
-                            gsum[1] += sv[8 + k]; gsq[1] = fmaf(sv[8 + k], sv[8 + k], gsq[1]);
-                        }
+                    if (has_stats) {     // of the STORED (rounded) values - what the GroupNorm that follows reads
+                        float s0[8], s1[8];
+                        chunk_to_f32<T>(pk0, s0); chunk_to_f32<T>(pk1, s1);
+                        st16.add8(0, s0); st16.add8(1, s1);
                     }
                 }
                 done = true;
@@ -561,8 +558,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                                 if (p.stats) {           // GroupNorm statistics of what was just stored (the rounded values)
                                     float sv[8];
                                     chunk_to_f32<T>(pk, sv);
-#pragma unroll
-                                    for (int q = 0; q < 8; ++q) { gsum[c] += sv[q]; gsq[c] = fmaf(sv[q], sv[q], gsq[c]); }
+                                    st16.add8(c, sv);
                                 }
                             }
                         }
@@ -582,11 +578,11 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             if (p.stats && n + 16 <= p.Cout && !parked) {
                 // reduce over the 16 pixel lanes (fr) of this quarter-wave in a fixed order, then one 16-byte store per
                 // (patch, M-wave, 16-channel slice): stats[b][partial][chunk][{sum, sumsq}]
-                const float r4[4] = {row16_sum(gsum[0]), row16_sum(gsq[0]), row16_sum(gsum[1]), row16_sum(gsq[1])};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
                 if (fr == 0) {
                     const int part = ((t.y0 / PATCH) * tiles_x + t.x0 / PATCH) * 4 + wm;
-                    float* dst = p.stats + (((int64_t)t.tb * p.stats_P + part) * (p.Cout >> 3) + (n >> 3)) * 2;
-                    *reinterpret_cast<float4*>(dst) = float4{r4[0], r4[1], r4[2], r4[3]};
+                    st16.store(p.stats, (int64_t)t.tb * p.stats_P + part, p.Cout, n, p.stats_gran);
                 }
             }
         }

@@ -273,6 +273,7 @@ static void fill_params(const nlc_conv_desc* d, KParams& p) {
     p.stats = nullptr; p.stats_P = 0;
     p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math;
     p.policy = d->policy; p.tuning = d->tuning;
+    p.stats_gran = d->stats_granule == 4 ? 4 : 8;
 }
 
 static bool desc_sane(const nlc_conv_desc* d, int dtype) {
@@ -362,6 +363,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(!d->res_upsample2x || (d->res && d->Hout % 2 == 0 && d->Wout % 2 == 0), "nlc_conv2d: res_upsample2x needs a residual and even Hout, Wout");
     NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
     NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_TALL, "nlc_conv2d: bad policy %d", d->policy);
+    NLC_REQUIRE(d->stats_granule == 0 || d->stats_granule == 4 || d->stats_granule == 8, "nlc_conv2d: stats_granule must be 0 (= 8), 4 or 8");
     if (d->policy > NLC_CONV_GENERIC && !nlc_has_experiments()) {
         nlc_set_error("nlc_conv2d: policy %d selects an experimental kernel; this library was built without --experiments", d->policy);
         return NLC_EUNSUPPORTED;
@@ -381,7 +383,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             Pfast = Phalo > 0 ? 0 : nlc_conv_fast_stats_partials(p, dtype);
             const int P = nlc_conv_narrow_ok(p, dtype) ? 0 : (Phalo > 0 ? Phalo : Pfast);
             NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
-            NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / 8) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
+            NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / p.stats_gran) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
+            NLC_REQUIRE(p.stats_gran == 8 || !nlc_has_experiments() || d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: the experimental kernels emit 8-channel statistics only");
             p.stats = (float*)d->stats_out; p.stats_P = P;
         }
         NLC_REQUIRE(!p.gn_coef || nlc_conv_tall_prologue_ok(p, dtype) || nlc_conv_halo_prologue_ok(p, dtype),

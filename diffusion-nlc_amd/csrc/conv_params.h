@@ -30,6 +30,32 @@ struct KParams {
     const float* gn_coef; int gn_act;   // conv_halo (bf16) only: input = act(a x + b) applied in LDS (nlc_conv_desc.gn_coef)
     int res_ups;        // res is [B][Hout/2][Wout/2][Cout]: output pixel (y, x) adds res pixel (y >> 1, x >> 1) (nlc_conv_desc.res_upsample2x)
     int math;           // NLC_MATH_* (nlc_conv_desc.math): f32 tensors only; F16X3 = weights packed as (hi, lo) f16 halves
+    int stats_gran;     // channels per chunk of `stats` (nlc_conv_desc.stats_granule): 8, or 4 for consumers whose groups are 4 channels wide
+};
+
+// ---- ride-along GroupNorm statistics of a lane's 16 consecutive output channels: (sum, sum of squares) of the STORED values per
+//      4-channel granule, accumulated over the pixels the lane stores; emitted per 8 channels (granule pairs added) or per 4.
+struct Stat16 {
+    float s[4], q[4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[k] = 0.f; q[k] = 0.f; }
+    }
+    __device__ __forceinline__ void add8(int half, const float (&sv)[8]) {      // channels 8 half .. 8 half + 7
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[2 * half + (k >> 2)] += sv[k]; q[2 * half + (k >> 2)] = fmaf(sv[k], sv[k], q[2 * half + (k >> 2)]); }
+    }
+    // values already reduced over whatever shares the partial; n = the lane's first channel
+    __device__ __forceinline__ void store(float* stats, int64_t row /* b * P + partial */, int Cout, int n, int gran) const {
+        if (gran == 4) {
+            float* dst = stats + (row * (Cout >> 2) + (n >> 2)) * 2;
+            *reinterpret_cast<float4*>(dst) = float4{s[0], q[0], s[1], q[1]};
+            *reinterpret_cast<float4*>(dst + 4) = float4{s[2], q[2], s[3], q[3]};
+        } else {
+            float* dst = stats + (row * (Cout >> 3) + (n >> 3)) * 2;
+            *reinterpret_cast<float4*>(dst) = float4{s[0] + s[1], q[0] + q[1], s[2] + s[3], q[2] + q[3]};
+        }
+    }
 };
 
 // ---- NLC_MATH_F16X3: an f32 operand as two f16 halves, x ~= hi + lo with hi = f16(x) (round to nearest), lo = f16(x - hi); the

@@ -2,6 +2,7 @@
 // sinusoidal embeddings and the Cin<=4 first-layer convolution.  All use 16-byte accesses on
 // the contiguous channel axis and grid-stride loops (<= 2048 workgroups).
 #include "common.h"
+#include "conv_params.h"
 
 namespace {
 
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              T* __restrict__ out, int Cin, int H, int W, int Cout,
                                                              int KH, int KW, int tiles_per_blk, int blks_per_img,
-                                                             float* __restrict__ stats) {
+                                                             float* __restrict__ stats, int stats_gran) {
     __shared__ __attribute__((aligned(16))) char patch[2][F1_PIX * F1_LD];
     const int K = KH * KW * Cin;
     const int HW = H * W;
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
     float cb[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) cb[k] = (bias && n + k < Cout) ? bias[n + k] : 0.f;
-    float gsum[2] = {0.f, 0.f}, gsq[2] = {0.f, 0.f};
+    Stat16 st16;
+    st16.zero();
     const int tile0 = blk * tiles_per_blk;
     const int ntile = (HW + F1_PIX - 1) / F1_PIX;
     const int pp = tid & 63, kq = tid >> 6;                  // patch builder: pixel pp, k = kq, kq+4, ...
@@ -246,8 +248,7 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
                         if (stats) {
                             float sv[8];
                             chunk_to_f32<T>(pk, sv);
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) { gsum[c] += sv[q]; gsq[c] = fmaf(sv[q], sv[q], gsq[c]); }
+                            st16.add8(c, sv);
                         }
                     }
                 } else {
@@ -258,15 +259,11 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
         }
     }
     if (stats) {             // host guarantees Cout % 16 == 0 and HW % 64 == 0 here: every lane contributed whole chunks
-        float r4[4] = {gsum[0], gsq[0], gsum[1], gsq[1]};
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) r4[q] += __shfl_xor(r4[q], o, 64);
-        if (fr == 0 && n < Cout) {
-            float* dst = stats + (((int64_t)b * blks_per_img + blk) * (Cout >> 3) + (n >> 3)) * 2;
-            *reinterpret_cast<float4*>(dst) = float4{r4[0], r4[1], r4[2], r4[3]};
-        }
+            for (int q = 0; q < 4; ++q) { st16.s[q] += __shfl_xor(st16.s[q], o, 64); st16.q[q] += __shfl_xor(st16.q[q], o, 64); }
+        if (fr == 0 && n < Cout) st16.store(stats, (int64_t)b * blks_per_img + blk, Cout, n, stats_gran);
     }
 }
 
@@ -367,7 +364,9 @@ extern "C" int nlc_conv_first_stats_partials(int Cin, int H, int W, int Cout, in
 
 extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const float* w, const float* bias, void* out_nhwc,
                               int B, int Cin, int H, int W, int Cout, int KH, int KW, int dtype,
-                              void* stats_out, int64_t stats_bytes, void* stream) {
+                              void* stats_out, int64_t stats_bytes, int stats_granule, void* stream) {
+    const int gran = stats_granule == 4 ? 4 : 8;
+    NLC_REQUIRE(stats_granule == 0 || stats_granule == 4 || stats_granule == 8, "nlc_conv_first: stats_granule must be 0, 4 or 8");
     NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_conv_first: bad dtype %d", dtype);
     NLC_REQUIRE(x_nchw && w && out_nhwc, "nlc_conv_first: null pointer");
     NLC_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "nlc_conv_first: bad dims");
@@ -380,7 +379,7 @@ extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const 
         if (want_stats) {
             NLC_REQUIRE(nb > 0 && (Cout % 16) == 0 && ((int64_t)H * W) % F1_PIX == 0,
                         "nlc_conv_first: stats_out given but this launch does not emit statistics (ask nlc_conv_first_stats_partials)");
-            NLC_REQUIRE(stats_bytes >= (int64_t)B * nb * (Cout / 8) * 2 * (int64_t)sizeof(float), "nlc_conv_first: stats_out too small");
+            NLC_REQUIRE(stats_bytes >= (int64_t)B * nb * (Cout / gran) * 2 * (int64_t)sizeof(float), "nlc_conv_first: stats_out too small");
         }
         if (nb > 0) {
             const int ntile = (int)(((int64_t)H * W + F1_PIX - 1) / F1_PIX);
@@ -388,7 +387,7 @@ extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const 
             const int nblk = (ntile + tpb - 1) / tpb;
             NLC_REQUIRE(!want_stats || nblk == nb, "nlc_conv_first: internal: partial count mismatch");
             NLC_SWITCH_16(dtype, hipLaunchKernelGGL(conv_first_mfma_kernel<T16>, dim3(nblk, B), dim3(NT), 0, (hipStream_t)stream, x_nchw, in_scale, w,
-                                                    bias, (T16*)out_nhwc, Cin, H, W, Cout, KH, KW, tpb, nb, (float*)stats_out));
+                                                    bias, (T16*)out_nhwc, Cin, H, W, Cout, KH, KW, tpb, nb, (float*)stats_out, gran));
             NLC_CHECK_LAUNCH("nlc_conv_first");
             return NLC_OK;
         }

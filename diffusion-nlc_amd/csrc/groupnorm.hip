@@ -306,26 +306,32 @@ struct GNCoefOut {        // optional second product of gn_finalize_chunks_kerne
 __global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __restrict__ s0, int P0, int C0,
                                                               const float* __restrict__ s1, int P1, int C1,
                                                               int gs, int G, int HW, float eps, float* __restrict__ stat,
-                                                              const GNCoefOut co, int TPG) {
+                                                              const GNCoefOut co, int TPG, int gran0, int gran1) {
     __shared__ double red[2][NT];
     __shared__ float s_mean[NT / 8], s_rstd[NT / 8];
     const int gpw = NT / TPG;                                  // groups per workgroup
     const int b = blockIdx.y, tid = threadIdx.x;
     const int gl = tid / TPG, l = tid - gl * TPG;
     const int g = blockIdx.x * gpw + gl;
-    const int nq0 = C0 / 8, nq1 = C1 / 8;
+    // each source carries its statistics per gran0 / gran1 (4 or 8) channels; a group is a whole number of chunks of either source
+    // (host-checked: gs and C0 are multiples of both granules), so walking the group's channels in steps of the source's own granule
+    // visits every chunk of the group exactly once
+    const int nq0 = C0 / gran0, nq1 = C1 > 0 ? C1 / gran1 : 0;
     double a = 0.0, c = 0.0;
     if (g < G) {
-        const int q0 = g * gs / 8, q1 = (g + 1) * gs / 8;       // chunk range of this group over cat(x0, x1)
-        for (int q = q0; q < q1; ++q) {
-            const bool second = q >= nq0;
+        int ch = g * gs;
+        const int ch1 = ch + gs;
+        while (ch < ch1) {
+            const bool second = ch >= C0;
             const float* src = second ? s1 : s0;
-            const int P = second ? P1 : P0, nq = second ? nq1 : nq0, qq = second ? q - nq0 : q;
+            const int gr = second ? gran1 : gran0;
+            const int P = second ? P1 : P0, nq = second ? nq1 : nq0, qq = (second ? ch - C0 : ch) / gr;
             const float* base = src + ((int64_t)b * P * nq + qq) * 2;
             for (int pp = l; pp < P; pp += TPG) {
                 const float2 v = *reinterpret_cast<const float2*>(base + (int64_t)pp * nq * 2);
                 a += (double)v.x; c += (double)v.y;
             }
+            ch += gr;
         }
     }
     red[0][tid] = a; red[1][tid] = c;
@@ -556,7 +562,7 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
 
 // threads per group of gn_finalize_chunks_kernel: ~16 (chunk, partial) items per thread, a power of two in [8, 256]
 static int finalize_tpg(int gs, int P0, int P1, int C0, int C1) {
-    const int64_t items = (int64_t)(gs / 8 > 0 ? gs / 8 : 1) * (P0 > P1 ? P0 : P1);
+    const int64_t items = (int64_t)(gs / 4 > 0 ? gs / 4 : 1) * (P0 > P1 ? P0 : P1);
     (void)C0; (void)C1;
     int tpg = 8;
     while (tpg < NT && (int64_t)tpg * 16 < items) tpg *= 2;
@@ -634,15 +640,17 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
 extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, float eps,
                                       const float* gamma, const float* beta, const float* scale, const float* shift,
                                       int ss_stride, int silu, void* out, void* workspace, int dtype,
-                                      const float* stats0, int P0, const float* stats1, int P1, void* stream) {
+                                      const float* stats0, int P0, int gran0, const float* stats1, int P1, int gran1, void* stream) {
+    const int g0 = gran0 == 4 ? 4 : 8, g1 = gran1 == 4 ? 4 : 8;
+    NLC_REQUIRE((gran0 == 0 || gran0 == 4 || gran0 == 8) && (gran1 == 0 || gran1 == 4 || gran1 == 8), "nlc_groupnorm_prestats: granules must be 0 (= 8), 4 or 8");
     NLC_REQUIRE(nlc_is16(dtype), "nlc_groupnorm_prestats: bf16 / f16 only (the f32 path computes its statistics itself)");
     NLC_REQUIRE(x0 && out && workspace && stats0 && P0 > 0, "nlc_groupnorm_prestats: null pointer");
     NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm_prestats: bad dims");
     NLC_REQUIRE((C1 == 0) == (x1 == nullptr) && (C1 == 0) == (stats1 == nullptr) && (C1 == 0 || P1 > 0),
                 "nlc_groupnorm_prestats: x1 / stats1 / C1 mismatch");
     const int C = C0 + C1;
-    NLC_REQUIRE(C % groups == 0 && (C / groups) % 8 == 0 && C0 % 8 == 0 && C1 % 8 == 0,
-                "nlc_groupnorm_prestats: group size %d and C0=%d, C1=%d must be multiples of 8", C / groups, C0, C1);
+    NLC_REQUIRE(C % groups == 0 && (C / groups) % g0 == 0 && (C1 == 0 || (C / groups) % g1 == 0) && C0 % 8 == 0 && C1 % 8 == 0,
+                "nlc_groupnorm_prestats: group size %d must be a multiple of the statistics granules (%d, %d) and C0=%d, C1=%d of 8", C / groups, g0, g1, C0, C1);
     NLC_REQUIRE(C / 8 <= NT, "nlc_groupnorm_prestats: C=%d too large for the one-chunk-per-thread apply kernel", C);
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_prestats: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_prestats: ss_stride < C");
@@ -658,7 +666,7 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
     const int tpg = finalize_tpg(p.gs, P0, P1, C0, C1);
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
-                       eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg);
+                       eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, g1);
 #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
     p.coef = coef;
 #endif
@@ -669,8 +677,10 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
 
 extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, int groups, float eps, const float* gamma,
                                      const float* beta, const float* scale, const float* shift, int ss_stride, int silu,
-                                     void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0,
+                                     void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0, int gran0,
                                      void* stream) {
+    const int g0 = gran0 == 4 ? 4 : 8;
+    NLC_REQUIRE(gran0 == 0 || gran0 == 4 || gran0 == 8, "nlc_groupnorm_pool2x2: granule must be 0 (= 8), 4 or 8");
     NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_groupnorm_pool2x2: bad dtype %d", dtype);
     const int per = nlc_is16(dtype) ? 8 : 4;
     NLC_REQUIRE(x && out_norm && out_x && workspace, "nlc_groupnorm_pool2x2: null pointer");
@@ -679,8 +689,8 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
     NLC_REQUIRE(C / per <= NT, "nlc_groupnorm_pool2x2: C=%d too large for the one-chunk-per-thread kernels", C);
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_pool2x2: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_pool2x2: ss_stride < C");
-    NLC_REQUIRE(!stats0 || (nlc_is16(dtype) && P0 > 0 && (C / groups) % 8 == 0),
-                "nlc_groupnorm_pool2x2: ride-along statistics are bf16 / f16 only, group size a multiple of 8");
+    NLC_REQUIRE(!stats0 || (nlc_is16(dtype) && P0 > 0 && (C / groups) % g0 == 0),
+                "nlc_groupnorm_pool2x2: ride-along statistics are bf16 / f16 only, group size a multiple of their granule");
     const int HW = H * W;
     GNParams p;
     fill_params(p, x, nullptr, C, 0, B, HW, groups, dtype);
@@ -692,7 +702,7 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
         float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
         const int tpg = finalize_tpg(p.gs, P0, 0, C, 0);
         hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
-                           groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg);
+                           groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, 8);
     #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
     p.coef = coef;
 #endif
@@ -711,20 +721,21 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
 }
 
 extern "C" int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
-                                  const float* scale, const float* shift, int ss_stride, const float* stats0, int P0,
-                                  const float* stats1, int P1, float* coef, void* stream) {
+                                  const float* scale, const float* shift, int ss_stride, const float* stats0, int P0, int gran0,
+                                  const float* stats1, int P1, int gran1, float* coef, void* stream) {
+    const int g0 = gran0 == 4 ? 4 : 8, g1 = gran1 == 4 ? 4 : 8;
     NLC_REQUIRE(coef && stats0 && P0 > 0, "nlc_groupnorm_coef: null pointer");
     NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm_coef: bad dims");
     NLC_REQUIRE((C1 == 0) == (stats1 == nullptr) && (C1 == 0 || P1 > 0), "nlc_groupnorm_coef: stats1 / C1 mismatch");
     const int C = C0 + C1;
-    NLC_REQUIRE(C % groups == 0 && (C / groups) % 8 == 0 && C0 % 8 == 0 && C1 % 8 == 0,
-                "nlc_groupnorm_coef: group size %d and C0=%d, C1=%d must be multiples of 8", C / groups, C0, C1);
+    NLC_REQUIRE(C % groups == 0 && (C / groups) % g0 == 0 && (C1 == 0 || (C / groups) % g1 == 0) && C0 % 8 == 0 && C1 % 8 == 0,
+                "nlc_groupnorm_coef: group size %d must be a multiple of the statistics granules and C0=%d, C1=%d of 8", C / groups, C0, C1);
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_coef: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_coef: ss_stride < C");
     GNCoefOut co{coef, gamma, beta, scale, shift, ss_stride};
     const int tpg = finalize_tpg(C / groups, P0, P1, C0, C1);
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, (hipStream_t)stream, stats0, P0, C0, stats1, P1, C1,
-                       C / groups, groups, HW, eps, (float*)nullptr, co, tpg);
+                       C / groups, groups, HW, eps, (float*)nullptr, co, tpg, g0, g1);
     NLC_CHECK_LAUNCH("nlc_groupnorm_coef");
     return NLC_OK;
 }

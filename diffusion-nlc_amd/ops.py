@@ -148,6 +148,19 @@ CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3, "wide": 4, "t
 CONV_POLICY = "auto"
 CONV_TUNING = 0              # nlc_conv_desc.tuning: schedule A/B switches for tools/ (0 in production)
 CONV_DEBUG = 0               # nlc_conv_desc.debug: bit 0 = verify the split-K arrival counters before every split launch (tests)
+# Ride-along GroupNorm statistics come per 8 output channels - or per 4 when the consumer's groups are 4 / 12 / 20 ... channels wide:
+# with the networks' 32 groups that is every <= 128-channel tensor (cfg 4's two highest-resolution levels, EDM's first layer),
+# whose GroupNorm otherwise pays a statistics pass over HBM (0.74 ms per NLC step of cfg 4).  A/B switch.
+STATS_GRANULE_4 = True
+
+
+def stats_granule(cout: int, groups_hint: int = 32) -> int:
+    gs = cout // groups_hint if cout % groups_hint == 0 else 0
+    return 4 if (STATS_GRANULE_4 and cout % 8 == 0 and gs and gs % 8 != 0 and gs % 4 == 0) else 8
+
+
+def _stats_gran_of(t: torch.Tensor, st: torch.Tensor) -> int:
+    return t.shape[-1] // st.shape[2]
 
 
 def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
@@ -227,8 +240,9 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel
         P = lib.nlc_conv2d_stats_partials(C.byref(d), dtype_enum(dt))
         if P > 0:
-            stats = torch.empty(B, P, pw.Cout // 8, 2, device=x0.device, dtype=torch.float32)
-            d.stats_out, d.stats_bytes = stats.data_ptr(), stats.numel() * 4
+            gran = 8 if CONV_POLICY in ("wide", "tall") else stats_granule(pw.Cout)      # (the experimental kernels emit per 8 only)
+            stats = torch.empty(B, P, pw.Cout // gran, 2, device=x0.device, dtype=torch.float32)
+            d.stats_out, d.stats_bytes, d.stats_granule = stats.data_ptr(), stats.numel() * 4, gran
     if is16(dt) or allow_split:      # split-K scratch for the few-tile / long-K levels (a cheap host query)
         need = lib.nlc_conv2d_workspace_bytes(C.byref(d), dtype_enum(dt))
         if need > 0:
@@ -281,11 +295,12 @@ def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
     out = torch.empty(B, H, W, Cout, device=x_nchw.device, dtype=dtype)
     stats = None
     P = lib.nlc_conv_first_stats_partials(Cin, H, W, Cout, k, k, dtype_enum(dtype))
+    gran = stats_granule(Cout)
     if P > 0:
-        stats = torch.empty(B, P, Cout // 8, 2, device=x_nchw.device, dtype=torch.float32)
+        stats = torch.empty(B, P, Cout // gran, 2, device=x_nchw.device, dtype=torch.float32)
     check(lib.nlc_conv_first(x_nchw.data_ptr(), _ptr(in_scale), w.data_ptr(), _ptr(bias), out.data_ptr(),
                              B, Cin, H, W, Cout, k, k, dtype_enum(dtype), _ptr(stats),
-                             0 if stats is None else stats.numel() * 4, _stream()), "nlc_conv_first")
+                             0 if stats is None else stats.numel() * 4, gran, _stream()), "nlc_conv_first")
     if stats is not None:
         out._nlc_stats = stats
     return out
@@ -342,15 +357,18 @@ def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
         if shift.stride(0) != ss_stride:
             raise ValueError("groupnorm: scale/shift must share a row stride")
     ws = _gn_workspace(x0.device, lib.nlc_groupnorm_workspace_bytes(B, HW, Ctot, groups))
-    if FUSED_GN_STATS and is16(dt) and (Ctot // groups) % 8 == 0 and C0 % 8 == 0 and Ctot // 8 <= 256:
+    if FUSED_GN_STATS and is16(dt) and Ctot % groups == 0 and C0 % 8 == 0 and C1 % 8 == 0 and Ctot // 8 <= 256:
         s0 = getattr(x0, "_nlc_stats", None)
         s1 = getattr(x1, "_nlc_stats", None) if x1 is not None else None
-        if s0 is not None and (x1 is None or s1 is not None):
+        gs = Ctot // groups
+        g0 = _stats_gran_of(x0, s0) if s0 is not None else 8
+        g1 = _stats_gran_of(x1, s1) if s1 is not None else 8
+        if s0 is not None and (x1 is None or s1 is not None) and gs % g0 == 0 and (x1 is None or gs % g1 == 0):
             # statistics came with the producing convolutions: finalize from their chunk sums + apply (2 passes, not 3)
             check(lib.nlc_groupnorm_prestats(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
                                              _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(),
-                                             ws.data_ptr(), dtype_enum(dt), s0.data_ptr(), s0.shape[1], _ptr(s1),
-                                             0 if s1 is None else s1.shape[1], _stream()), "nlc_groupnorm_prestats")
+                                             ws.data_ptr(), dtype_enum(dt), s0.data_ptr(), s0.shape[1], g0, _ptr(s1),
+                                             0 if s1 is None else s1.shape[1], g1, _stream()), "nlc_groupnorm_prestats")
             return out
     check(lib.nlc_groupnorm(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
                             _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(), ws.data_ptr(),
@@ -379,12 +397,16 @@ def groupnorm_pool2x2(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Opti
         if shift.stride(0) != ss_stride:
             raise ValueError("groupnorm_pool2x2: scale/shift must share a row stride")
     ws = _gn_workspace(x.device, lib.nlc_groupnorm_workspace_bytes(B, H * W, Cc, groups))
-    s0 = None
-    if FUSED_GN_STATS and is16(dt) and (Cc // groups) % 8 == 0:
+    s0, g0 = None, 8
+    if FUSED_GN_STATS and is16(dt) and Cc % groups == 0:
         s0 = getattr(x, "_nlc_stats", None)
+        if s0 is not None:
+            g0 = _stats_gran_of(x, s0)
+            if (Cc // groups) % g0:
+                s0 = None
     check(lib.nlc_groupnorm_pool2x2(x.data_ptr(), Cc, B, H, W, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift),
                                     ss_stride, 1 if silu else 0, out_h.data_ptr(), out_x.data_ptr(), ws.data_ptr(), dtype_enum(dt),
-                                    _ptr(s0), 0 if s0 is None else s0.shape[1], _stream()), "nlc_groupnorm_pool2x2")
+                                    _ptr(s0), 0 if s0 is None else s0.shape[1], g0, _stream()), "nlc_groupnorm_pool2x2")
     return out_h, out_x
 
 
@@ -414,11 +436,15 @@ def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1
     B, C0 = x0.shape[0], x0.shape[-1]
     C1 = 0 if x1 is None else x1.shape[-1]
     Ctot = C0 + C1
-    if (Ctot // groups) % 8 or C0 % 8 or C1 % 8 or Ctot % groups:
+    if C0 % 8 or C1 % 8 or Ctot % groups:
         return None
     s0 = getattr(x0, "_nlc_stats", None)
     s1 = getattr(x1, "_nlc_stats", None) if x1 is not None else None
     if s0 is None or (x1 is not None and s1 is None):
+        return None
+    g0 = _stats_gran_of(x0, s0)
+    g1 = _stats_gran_of(x1, s1) if s1 is not None else 8
+    if (Ctot // groups) % g0 or (x1 is not None and (Ctot // groups) % g1):
         return None
     HW = x0.numel() // (B * C0)
     ss_stride = 0
@@ -428,7 +454,7 @@ def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1
             raise ValueError("groupnorm_coef: scale/shift must be row-strided f32 views sharing a row stride")
     coef = torch.empty(B * Ctot * 2 + 128, device=x0.device, dtype=torch.float32)        # + 512 bytes: the consumer's DMA reads whole 1-KiB pieces
     check(lib.nlc_groupnorm_coef(C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), ss_stride,
-                                 s0.data_ptr(), s0.shape[1], _ptr(s1), 0 if s1 is None else s1.shape[1], coef.data_ptr(),
+                                 s0.data_ptr(), s0.shape[1], g0, _ptr(s1), 0 if s1 is None else s1.shape[1], g1, coef.data_ptr(),
                                  _stream()), "nlc_groupnorm_coef")
     return coef
 

@@ -151,6 +151,8 @@ typedef struct nlc_conv_desc {
     int32_t res_upsample2x; /* 1: res is [B][Hout/2][Wout/2][Cout] and output pixel (y, x) adds res pixel (y/2, x/2) - the        */
                          /* skip branch x_upd(x) of an up-sampling ResBlock (src/unet_adm.py:186-190, nearest-2x Upsample) read    */
                          /* in place of a materialised upsampled copy.  Hout, Wout must be even.                                  */
+    int32_t stats_granule; /* channels per chunk of stats_out: 0 or 8 = per 8 channels, 4 = per 4 (for a GroupNorm whose groups are 4 or 12 ...  */
+                         /* channels wide: 128 channels in 32 groups); stats_out is then float [B][P][Cout/4][2].                       */
     int32_t math;        /* NLC_MATH_* (0 = the dtype's native MFMA).  NLC_MATH_F16X3 needs dtype NLC_F32 and `w` packed by          */
                          /* nlc_pack_conv_weights_ex(..., NLC_MATH_F16X3): the packed tensor then holds (hi, lo) f16 halves of every  */
                          /* weight in the k order the kernels read, same byte size as the f32 packing.                                 */
@@ -177,8 +179,8 @@ int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype);
 int nlc_conv_first(const float* x_nchw, const float* in_scale /*[B] or NULL*/,
                    const float* w, const float* bias, void* out_nhwc,
                    int B, int Cin, int H, int W, int Cout, int KH, int KW,
-                   int dtype, void* stats_out /* or NULL */, int64_t stats_bytes, void* stream);
-/* stats_out: GroupNorm statistics of the output, float [B][P][Cout/8][2] as in nlc_conv_desc.stats_out, with
+                   int dtype, void* stats_out /* or NULL */, int64_t stats_bytes, int stats_granule /* 0 | 8 | 4 */, void* stream);
+/* stats_out: GroupNorm statistics of the output, float [B][P][Cout/granule][2] as in nlc_conv_desc.stats_out, with
  * P = nlc_conv_first_stats_partials(...) > 0 (bf16, KH*KW*Cin <= 32, Cout <= 256 and a multiple of 16, H*W a
  * multiple of 64: the launches that take the matrix-core kernel). */
 int nlc_conv_first_stats_partials(int Cin, int H, int W, int Cout, int KH, int KW, int dtype);
@@ -204,7 +206,9 @@ int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B
                            int groups, float eps, const float* gamma, const float* beta,
                            const float* scale, const float* shift, int ss_stride,
                            int silu, void* out, void* workspace, int dtype,
-                           const float* stats0, int P0, const float* stats1, int P1, void* stream);
+                           const float* stats0, int P0, int granule0, const float* stats1, int P1, int granule1, void* stream);
+/* granule0 / granule1: channels per chunk of stats0 / stats1 (0 or 8, or 4 - nlc_conv_desc.stats_granule of the producer); the
+ * group size must be a multiple of both. */
 
 /* The two branches of a down-sampling ResBlock from ONE read of x (src/unet_adm.py:193-195: h = in_rest(x); h = h_upd(h);
  * x = x_upd(x), both AvgPool2d(2)):  out_norm = avgpool2x2(act(GroupNorm(x) (FiLM))),  out_x = avgpool2x2(x), both
@@ -213,15 +217,16 @@ int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B
  * nlc_avgpool2x2; bf16: the pooled mean is taken of the f32 activations (one rounding less).  Same workspace as nlc_groupnorm. */
 int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, int groups, float eps, const float* gamma,
                           const float* beta, const float* scale, const float* shift, int ss_stride, int silu,
-                          void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0, void* stream);
+                          void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0, int granule0,
+                          void* stream);
 
 /* The per-(image, channel) coefficients of the same normalisation, for the convolution that applies it in its LDS prologue
  * (nlc_conv_desc.gn_coef): coef[b][c] = (a, b) with  a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift,
  * statistics from the producing convolutions' epilogues exactly as in nlc_groupnorm_prestats (same f64 fixed-order fold).
  * coef: float [B][C0+C1][2] (+ >= 512 bytes of slack behind it for the consumer's DMA). */
 int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
-                       const float* scale, const float* shift, int ss_stride, const float* stats0, int P0,
-                       const float* stats1, int P1, float* coef, void* stream);
+                       const float* scale, const float* shift, int ss_stride, const float* stats0, int P0, int granule0,
+                       const float* stats1, int P1, int granule1, float* coef, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-head softmax attention on token-major tensors (flash style, no TxT matrix in HBM).

@@ -509,10 +509,11 @@ def test_ride_along_statistics_under_the_production_dispatch(case, t16):
     finally:
         ops.CONV_POLICY = old
     st = getattr(y, "_nlc_stats", None)
-    assert st is not None and st.shape == (B, P_expect, Cout // 8, 2), (what, None if st is None else st.shape)
+    gran = ops.stats_granule(Cout)                                   # 4 for the 128-channel case (32 groups of 4), else 8
+    assert st is not None and st.shape == (B, P_expect, Cout // gran, 2), (what, None if st is None else st.shape)
     ref = F.conv2d(_rt(x, t16), _rt(w, t16), b, padding=1) + _rt(res, t16)
     _close(y.permute(0, 3, 1, 2), ref, 2e-2, what)
-    ch = y.float().cpu().view(B, H * W, Cout // 8, 8).double()
+    ch = y.float().cpu().view(B, H * W, Cout // gran, gran).double()
     got = st.double().sum(dim=1).cpu()
     s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
     assert (got[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0), what
@@ -528,6 +529,65 @@ def test_ride_along_statistics_under_the_production_dispatch(case, t16):
     scale = refn.abs().max().item()
     assert (fused.float().cpu() - plain.float().cpu()).abs().max().item() <= 2e-2 * scale, what
     assert (fused.float().cpu() - refn).abs().max().item() <= 2e-2 * scale, what
+
+
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+@pytest.mark.parametrize("policy", ["auto", "halo"])
+def test_groupnorm_with_four_channel_groups_uses_ride_along_statistics(policy, t16):
+    """128 channels in 32 groups = 4 channels per group (cfg 4's two highest-resolution levels, EDM's first layer): the producing
+    convolutions emit their statistics per 4 channels (nlc_conv_desc.stats_granule), GroupNorm folds them - alone, pooled
+    (groupnorm_pool2x2) and over the concatenation of two such tensors (8-channel groups made of two 4-channel chunks) - and agrees
+    with the statistics-pass path and with torch."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(41)
+    B, Cin, H, W, C = 2, 64, 32, 64, 128
+    x = torch.randn(B, Cin, H, W, generator=g)
+    old = ops.CONV_POLICY
+    ops.CONV_POLICY = policy
+    try:
+        ys = []
+        for k in range(2):
+            w = torch.randn(C, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+            b = torch.randn(C, generator=g) * 0.3 + 0.4 * k
+            ys.append(ops.conv2d(_nhwc(x, t16), ops.pack_conv(w, b, t16, _dev())))
+    finally:
+        ops.CONV_POLICY = old
+    for y in ys:
+        st = getattr(y, "_nlc_stats", None)
+        assert st is not None and st.shape[2] == C // 4, "expected statistics per 4 channels"
+        ch = y.float().cpu().view(B, H * W, C // 4, 4).double()
+        got = st.double().sum(dim=1).cpu()
+        assert (got[..., 0] - ch.sum(dim=(1, 3))).abs().max() <= 3e-3 * max(ch.sum(dim=(1, 3)).abs().max().item(), 1.0)
+        assert ((got[..., 1] - (ch ** 2).sum(dim=(1, 3))) / (ch ** 2).sum(dim=(1, 3))).abs().max() <= 2e-3
+    tol = 2e-2 if t16 == torch.bfloat16 else 3e-3
+
+    def both(fn):
+        fused = fn()
+        ops.FUSED_GN_STATS = False
+        try:
+            plain = fn()
+        finally:
+            ops.FUSED_GN_STATS = True
+        return fused, plain
+
+    gamma, beta = torch.randn(2 * C, generator=g).to(_dev()), torch.randn(2 * C, generator=g).to(_dev())
+    # one 128-channel tensor: groups of 4
+    f1, p1 = both(lambda: ops.groupnorm(ys[0], gamma[:C], beta[:C], groups=32, eps=1e-6, silu=True))
+    ref1 = F.silu(F.group_norm(ys[0].float().cpu().permute(0, 3, 1, 2), 32, gamma[:C].cpu(), beta[:C].cpu(), eps=1e-6)).permute(0, 2, 3, 1)
+    sc = ref1.abs().max().item()
+    assert (f1.float().cpu() - p1.float().cpu()).abs().max().item() <= tol * sc and (f1.float().cpu() - ref1).abs().max().item() <= tol * sc
+    # cat of two: 256 channels, groups of 8 = two 4-channel chunks each
+    f2, p2 = both(lambda: ops.groupnorm(ys[0], gamma, beta, groups=32, eps=1e-5, silu=False, x1=ys[1]))
+    cat = torch.cat([ys[0].float().cpu(), ys[1].float().cpu()], dim=-1).permute(0, 3, 1, 2)
+    ref2 = F.group_norm(cat, 32, gamma.cpu(), beta.cpu(), eps=1e-5).permute(0, 2, 3, 1)
+    sc = ref2.abs().max().item()
+    assert (f2.float().cpu() - p2.float().cpu()).abs().max().item() <= tol * sc and (f2.float().cpu() - ref2).abs().max().item() <= tol * sc
+    # both branches of a down-sampling block from one read
+    (h3, x3), (h3p, x3p) = both(lambda: ops.groupnorm_pool2x2(ys[0], gamma[:C], beta[:C], groups=32, eps=1e-6, silu=True))
+    refh = F.avg_pool2d(ref1.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    sc = refh.abs().max().item()
+    assert (h3.float().cpu() - h3p.float().cpu()).abs().max().item() <= tol * sc and (h3.float().cpu() - refh).abs().max().item() <= tol * sc
+    assert torch.equal(x3, x3p)
 
 
 def test_pack_conv_weights_abi_matches_the_host_packing_rule():
@@ -711,11 +771,12 @@ def test_conv2d_halo_kernel_split_k(case, t16):
     st = getattr(got, "_nlc_stats", None)
     tiles = B * (Ho // 16) * (Wo // 16) * (Cout // 128)
     if tiles * case["ks"] >= 128:
-        assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 16) * 4, Cout // 8, 2), "the halo kernel did not take this launch"
+        gran = ops.stats_granule(Cout)
+        assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 16) * 4, Cout // gran, 2), "the halo kernel did not take this launch"
     _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (halo split-K)")
     assert (got.float() - plain.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
     if st is not None:
-        ch = got.float().cpu().view(B, Ho * Wo, Cout // 8, 8).double()
+        ch = got.float().cpu().view(B, Ho * Wo, Cout // gran, gran).double()
         tot = st.double().sum(dim=1).cpu()
         s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
         assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
