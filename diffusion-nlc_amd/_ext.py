@@ -113,7 +113,7 @@ SIGNATURES = {
     "nlc_groupnorm": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "nlc_groupnorm_prestats": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "nlc_groupnorm_pool2x2": (C.c_int, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
-    "nlc_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "nlc_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "nlc_avgpool2x2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nlc_upsample2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nlc_pad_rb": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

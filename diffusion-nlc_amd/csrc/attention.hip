@@ -65,7 +65,7 @@ template <typename T, int D> struct AttnCfg {
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int Tn, int H) {
+__global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int Tn, int H, int base2) {
     using C = AttnCfg<T, D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float mn = fmaxf(mrow[r], tmax[r]);
-            alpha[r] = (sizeof(T) == 4) ? expf(mrow[r] - mn) : __expf(mrow[r] - mn);
+            alpha[r] = base2 ? ((sizeof(T) == 4) ? exp2f(mrow[r] - mn) : __builtin_amdgcn_exp2f(mrow[r] - mn))
+                             : ((sizeof(T) == 4) ? expf(mrow[r] - mn) : __expf(mrow[r] - mn));
             mrow[r] = mn;
             lrow[r] *= alpha[r];
         }
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
         for (int j = 0; j < C::NNT; ++j) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = (sizeof(T) == 4) ? expf(s[j][r] - mrow[r]) : __expf(s[j][r] - mrow[r]);
+                const float pv = base2 ? ((sizeof(T) == 4) ? exp2f(s[j][r] - mrow[r]) : __builtin_amdgcn_exp2f(s[j][r] - mrow[r]))
+                                       : ((sizeof(T) == 4) ? expf(s[j][r] - mrow[r]) : __expf(s[j][r] - mrow[r]));
                 lrow[r] += pv;
                 // P scratch: row 4*fq+r, col 16*j+fr
                 const int prow = fq * 4 + r, pcol = j * 16 + fr;
@@ -262,7 +264,19 @@ __device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_base)
                  : "memory");
 }
 
-template <typename T>
+// Softmax bookkeeping, built around what bounds this kernel: at 64 channels per head a 64-key tile is 16 MFMAs (512 matrix cycles per
+// wave) against one v_exp_f32 per score (8 issue cycles each) plus whatever else runs per score, so every per-score VALU instruction
+// besides the exponential costs matrix utilisation (round 2: 11.4 VALU per MFMA, matrix pipe 28 % busy).  Per score there is now
+// the exponential and half a convert, nothing else:
+//   * BASE2 (log2 e folded into the q projection at pack time, nlc_attention(logit_log2 = 1)): p = 2^s needs no multiply;
+//   * no per-tile maximum subtraction: softmax is invariant to the offset, and 2^s cannot overflow while the running maximum stays
+//     below 2^64, so the offset `moff` stays 0 (wave-uniformly) until a lane's running maximum leaves [-64, 64] log2 units - only then
+//     does that wave take the general path (subtract, rescale O and l) for the rest of its rows; the tile maximum itself is still
+//     computed (16 v_max3), it is what detects the excursion;
+//   * the row sums l come from the matrix pipe: one more MFMA per k-step with an all-ones A operand and the same P^T fragment
+//     (every row of the result is sum_k P[k][q]; only register 0 is kept consistent), instead of 32 adds per tile - and they sum
+//     the ROUNDED probabilities the PV product uses.
+template <typename T, bool BASE2>
 __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -325,11 +339,13 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
 #pragma unroll
         for (int db = 0; db < 2; ++db) { vo[ks][db][0] = voff(ks, db, 0); vo[ks][db][1] = voff(ks, db, 1); }
 
-    f32x16_t o0, o1;                                     // O^T blocks: d = 32 db + (reg & 3) + 8 (reg >> 2) + 4 h, query on the lane
+    f32x16_t o0, o1, lacc;                               // O^T blocks: d = 32 db + (reg & 3) + 8 (reg >> 2) + 4 h, query on the lane; lacc[0] = row sum
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m = -1e30f, l = 0.f;                           // running maximum (of score * log2 e) and this lane's half of the row sum
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; lacc[r] = 0.f; }
+    float mrun = -1e30f, moff = 0.f;                     // running maximum and current offset of this lane's query, log2 units
     constexpr float L2E = 1.44269504088896340736f;
+    const unsigned one2 = std::is_same<T, bf16_raw>::value ? 0x3F803F80u : 0x3C003C00u;      // two 1.0 in T
+    const uint4 ones = make_uint4(one2, one2, one2, one2);
 
     const int ntiles = Tn / (FKV * F_SUB);
     issue(0, 0);
@@ -356,11 +372,9 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
             s0 = Mfma16<T>::run32(ka, qf[s], s0);
             s1 = Mfma16<T>::run32(kc, qf[s], s1);
         }
-        // ---- online softmax, lane-local except one half exchange for the maximum
-        // Row maximum of the RAW scores with v_max3_f32 from inline asm: fmaxf() on an MFMA output makes hipcc insert a
-        // quieting v_max(x, x) per element first (32 extra VALU per tile in a loop that is VALU-issue bound).  The first
-        // maximum is plain C so that the compiler itself pads the MFMA -> VALU read hazard of both accumulators; every asm
-        // statement depends on it through `tm`.
+        // ---- tile maximum of the RAW scores (v_max3_f32 from inline asm: fmaxf() on an MFMA output makes hipcc insert a quieting
+        // v_max(x, x) per element first).  The first maximum is plain C so that the compiler itself pads the MFMA -> VALU read
+        // hazard of both accumulators; every asm statement depends on it through `tm`.
         float tm = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(s0[r]), "v"(s1[r]));
@@ -368,22 +382,34 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tm), __float_as_uint(tm), false, false);
             tm = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));      // lanes l and l ^ 32 hold the two halves of one row
         }
-        const float mn = fmaxf(m, tm * L2E);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        m = mn;
-        l *= alpha;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {       // wave-uniform: after the first tiles the maximum rarely moves
+        const float mnew = fmaxf(mrun, BASE2 ? tm : tm * L2E);
+        // an offset is (re)chosen when the running maximum leaves [-64, 64] relative to it; on the first tile also when it lies
+        // far BELOW (all logits very negative: 2^s would underflow)
+        const float rel = mnew - moff;
+        const bool need = rel > 64.f || (mrun < -1e29f && rel < -64.f);
+        mrun = mnew;
+        if (__builtin_amdgcn_ballot_w64(need || moff != 0.f) != 0) {
+            // general path (rare): some query of this wave carries an offset - subtract it IN PLACE, then the common exponentials
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                const float mo = need ? mnew : moff;
+                // nothing is accumulated before the first tile; afterwards need implies mo > moff, so alpha < 1
+                const float alpha = (lacc[0] == 0.f && o0[0] == 0.f) ? 1.f : __builtin_amdgcn_exp2f(moff - mo);
+                moff = mo;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                lacc[0] *= alpha;
+            }
+            const float sub = BASE2 ? moff : moff * (1.0f / L2E);       // in the units of the raw scores
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] -= sub; s1[r] -= sub; }
         }
+        // one exponential per score (BASE2: nothing else; natural logits: the log2 e multiply)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], L2E, -mn));
-            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], L2E, -mn));
-            l += s0[r];
-            l += s1[r];
+            s0[r] = __builtin_amdgcn_exp2f(BASE2 ? s0[r] : s0[r] * L2E);
+            s1[r] = __builtin_amdgcn_exp2f(BASE2 ? s1[r] : s1[r] * L2E);
         }
-        // ---- O^T += V^T P^T : P^T k-steps come straight from the score registers
+        // ---- O^T += V^T P^T and l += 1^T P^T : P^T k-steps come straight from the score registers
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 pf;
@@ -398,6 +424,7 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
                 for (int j = 0; j < 8; ++j) ph[j] = (f16_raw)((ks < 2 ? s0 : s1)[(ks & 1) * 8 + j]);
                 pf = __builtin_bit_cast(uint4, ph);
             }
+            lacc = Mfma16<T>::run32(ones, pf, lacc);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vt + vo[ks][db][0]));
@@ -415,12 +442,8 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own DMA pieces of tile t + 1 landed ...
         __syncthreads();                                       // ... and everybody's are published; tile t's stage is free
     }
-    // ---- finish: full row sum = both halves, normalise, store 4 consecutive channels (8 bytes) per register quad
-    {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
-        l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const float inv = 1.0f / l;
+    // ---- finish: normalise by the row sum (every row of lacc is the same sum), store 4 consecutive channels (8 bytes) per register quad
+    const float inv = 1.0f / lacc[0];
     T* op = out + ((int64_t)b * Tn + q0 + q) * ((int64_t)H * 64) + (int64_t)hd * 64 + 4 * h;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -433,38 +456,38 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
         }
 }
 
-template <typename T>
+template <typename T, bool BASE2>
 int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel<T, BASE2>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
     });
-    hipLaunchKernelGGL(attn_d64_kernel<T>, dim3((Tn / FQ_ROWS) * H * B), dim3(FQ_WAVES * 64), F_LDS, st, (const T*)qkv, (T*)out, Tn, H);
+    hipLaunchKernelGGL((attn_d64_kernel<T, BASE2>), dim3((Tn / FQ_ROWS) * H * B), dim3(FQ_WAVES * 64), F_LDS, st, (const T*)qkv, (T*)out, Tn, H);
     NLC_CHECK_LAUNCH("nlc_attention(d64)");
     return NLC_OK;
 }
 
 template <typename T, int D>
-int launch(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
+int launch(const void* qkv, void* out, int B, int Tn, int H, int base2, hipStream_t st) {
     using C = AttnCfg<T, D>;
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     });
     dim3 grid(cdiv(Tn, QB), H, B);
-    hipLaunchKernelGGL((attn_kernel<T, D>), grid, dim3(NTHREADS), C::LDS, st, (const T*)qkv, (T*)out, B, Tn, H);
+    hipLaunchKernelGGL((attn_kernel<T, D>), grid, dim3(NTHREADS), C::LDS, st, (const T*)qkv, (T*)out, B, Tn, H, base2);
     NLC_CHECK_LAUNCH("nlc_attention");
     return NLC_OK;
 }
 
 template <typename T>
-int dispatch(const void* qkv, void* out, int B, int Tn, int H, int D, hipStream_t st) {
+int dispatch(const void* qkv, void* out, int B, int Tn, int H, int D, int base2, hipStream_t st) {
     switch (D) {
-        case 32: return launch<T, 32>(qkv, out, B, Tn, H, st);
-        case 64: return launch<T, 64>(qkv, out, B, Tn, H, st);
-        case 128: return launch<T, 128>(qkv, out, B, Tn, H, st);
-        case 256: return launch<T, 256>(qkv, out, B, Tn, H, st);
-        case 512: return launch<T, 512>(qkv, out, B, Tn, H, st);
+        case 32: return launch<T, 32>(qkv, out, B, Tn, H, base2, st);
+        case 64: return launch<T, 64>(qkv, out, B, Tn, H, base2, st);
+        case 128: return launch<T, 128>(qkv, out, B, Tn, H, base2, st);
+        case 256: return launch<T, 256>(qkv, out, B, Tn, H, base2, st);
+        case 512: return launch<T, 512>(qkv, out, B, Tn, H, base2, st);
         default:
             nlc_set_error("nlc_attention: head dim %d unsupported (32,64,128,256,512)", D);
             return NLC_EUNSUPPORTED;
@@ -473,15 +496,19 @@ int dispatch(const void* qkv, void* out, int B, int Tn, int H, int D, hipStream_
 
 }  // namespace
 
-extern "C" int nlc_attention(const void* qkv, void* out, int B, int T, int H, int D, int dtype, void* stream) {
+extern "C" int nlc_attention(const void* qkv, void* out, int B, int T, int H, int D, int dtype, int logit_log2, void* stream) {
+    const int base2 = logit_log2 ? 1 : 0;
     NLC_REQUIRE(qkv && out, "nlc_attention: null pointer");
     NLC_REQUIRE(B > 0 && T > 0 && H > 0 && D > 0, "nlc_attention: bad dims");
     NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_attention: bad dtype %d", dtype);
     NLC_REQUIRE(H <= 65535 && B <= 65535 && (int64_t)B * H * (T / 64 + 1) < (1ll << 31), "nlc_attention: grid too large");
     // the ADM-256 shapes (64 channels per head, T = 1024 / 256): register-resident kernel above
-    if (nlc_is16(dtype) && D == 64 && T % FQ_ROWS == 0)
-        return dtype == NLC_BF16 ? launch_d64<bf16_raw>(qkv, out, B, T, H, (hipStream_t)stream) : launch_d64<f16_raw>(qkv, out, B, T, H, (hipStream_t)stream);
-    if (dtype == NLC_BF16) return dispatch<bf16_raw>(qkv, out, B, T, H, D, (hipStream_t)stream);
-    if (dtype == NLC_F16) return dispatch<f16_raw>(qkv, out, B, T, H, D, (hipStream_t)stream);
-    return dispatch<float>(qkv, out, B, T, H, D, (hipStream_t)stream);
+    if (nlc_is16(dtype) && D == 64 && T % FQ_ROWS == 0) {
+        if (dtype == NLC_BF16)
+            return base2 ? launch_d64<bf16_raw, true>(qkv, out, B, T, H, (hipStream_t)stream) : launch_d64<bf16_raw, false>(qkv, out, B, T, H, (hipStream_t)stream);
+        return base2 ? launch_d64<f16_raw, true>(qkv, out, B, T, H, (hipStream_t)stream) : launch_d64<f16_raw, false>(qkv, out, B, T, H, (hipStream_t)stream);
+    }
+    if (dtype == NLC_BF16) return dispatch<bf16_raw>(qkv, out, B, T, H, D, base2, (hipStream_t)stream);
+    if (dtype == NLC_F16) return dispatch<f16_raw>(qkv, out, B, T, H, D, base2, (hipStream_t)stream);
+    return dispatch<float>(qkv, out, B, T, H, D, base2, (hipStream_t)stream);
 }

@@ -66,8 +66,10 @@ class _UNetBlock:
             idx = torch.arange(3 * c)
             s_, c_ = idx // c, idx % c
             perm = c_ * 3 + s_                      # reshape(n, C, 3, T).unbind(2): channel = c*3 + {q,k,v} (:199-200)
-            scale = torch.ones(3 * c)
+            scale = torch.ones(3 * c, dtype=torch.float64)
             scale[: 2 * c] = float(c) ** -0.25      # k / sqrt(C) (:127) split evenly over q and k
+            f, self.base2 = ops.attention_logit_scale(dtype)
+            scale[:c] *= f
             self.attn = (Norm(sd, p + ".norm2", device, _groups(c), GN_EPS),
                          pack(sd, p + ".qkv", dtype, device, row_perm=perm, row_scale=scale),
                          pack(sd, p + ".proj", dtype, device))
@@ -92,7 +94,7 @@ class _UNetBlock:
         if self.attn is not None:
             norm, qkv, proj = self.attn
             B, H, W, C = x.shape
-            a = ops.attention(ops.conv2d(norm(x, silu=False), qkv).view(B, H * W, 3 * C), 1)
+            a = ops.attention(ops.conv2d(norm(x, silu=False), qkv).view(B, H * W, 3 * C), 1, base2=self.base2)
             x = ops.conv2d(a.view(B, H, W, C), proj, res=x, out_scale=SKIP_SCALE)
         return x
 

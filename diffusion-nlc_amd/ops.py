@@ -459,14 +459,27 @@ def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1
     return coef
 
 
-def attention(qkv: torch.Tensor, heads: int) -> torch.Tensor:
-    """qkv: [B,T,3*H*D] laid out [3][H][D]; returns [B,T,H*D]."""
+LOG2E = 1.4426950408889634
+
+
+def attention_logit_scale(spec) -> tuple:
+    """(extra factor for the q rows of a qkv projection's row_scale, the matching ``base2`` flag of ``attention``): 16-bit models fold
+    log2(e) into q at pack time so that the kernel exponentiates with 2^x and no multiply; f32 models keep natural logits and e^x
+    (the reference's op order)."""
+    return (LOG2E, True) if (isinstance(spec, torch.dtype) and is16(spec) and ATTN_BASE2) else (1.0, False)
+
+
+ATTN_BASE2 = True            # A/B switch of attention_logit_scale (takes effect when a model is (re)packed)
+
+
+def attention(qkv: torch.Tensor, heads: int, base2: bool = False) -> torch.Tensor:
+    """qkv: [B,T,3*H*D] laid out [3][H][D]; returns [B,T,H*D].  ``base2``: the logits are in log2 units (attention_logit_scale)."""
     lib = _ext.load()
     _need(qkv, qkv.dtype, "attention qkv")
     B, T, C3 = qkv.shape
     D = C3 // (3 * heads)
     out = torch.empty(B, T, heads * D, device=qkv.device, dtype=qkv.dtype)
-    check(lib.nlc_attention(qkv.data_ptr(), out.data_ptr(), B, T, heads, D, dtype_enum(qkv.dtype), _stream()),
+    check(lib.nlc_attention(qkv.data_ptr(), out.data_ptr(), B, T, heads, D, dtype_enum(qkv.dtype), 1 if base2 else 0, _stream()),
           "nlc_attention")
     return out
 

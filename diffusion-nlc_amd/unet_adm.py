@@ -101,15 +101,17 @@ class _Attention:
         else:                                # legacy [head][q|k|v][ch] (:347) -> [q|k|v][head][ch]
             s_, h_, c_ = idx // (heads * d), (idx // d) % heads, idx % d
             perm = h_ * (3 * d) + s_ * d + c_
-        scale = torch.ones(ch3)
+        scale = torch.ones(ch3, dtype=torch.float64)
         scale[: 2 * c] = 1.0 / math.sqrt(math.sqrt(d))      # q and k each scaled by ch^-1/4 (:348-351)
+        f, self.base2 = ops.attention_logit_scale(dtype)
+        scale[:c] *= f                                       # 16-bit models: log2(e) rides along on q, the kernel uses 2^x
         self.qkv = pack(sd, p + ".qkv", dtype, device, row_perm=perm, row_scale=scale)
         self.proj = pack(sd, p + ".proj_out", dtype, device)
 
     def __call__(self, x):
         B, H, W, C = x.shape
         qkv = ops.conv2d(self.norm(x, silu=False), self.qkv)
-        a = ops.attention(qkv.view(B, H * W, 3 * C), self.heads)
+        a = ops.attention(qkv.view(B, H * W, 3 * C), self.heads, base2=self.base2)
         return ops.conv2d(a.view(B, H, W, C), self.proj, res=x)
 
 

@@ -64,15 +64,17 @@ class _AttnBlock:
         self.norm = Norm(sd, p + ".norm", device, GN_GROUPS, GN_EPS)
         w = torch.cat([sd[f"{p}.{n}.weight"] for n in ("q", "k", "v")], 0)
         b = torch.cat([sd[f"{p}.{n}.bias"] for n in ("q", "k", "v")], 0)
-        scale = torch.ones(3 * c)
+        scale = torch.ones(3 * c, dtype=torch.float64)
         scale[: 2 * c] = float(c) ** -0.25                  # w_ * c^-1/2 (:177) split evenly over q and k
+        f, self.base2 = ops.attention_logit_scale(dtype)
+        scale[:c] *= f
         self.qkv = pack_w(w, b, dtype, device, row_scale=scale)
         self.proj = pack(sd, p + ".proj_out", dtype, device)
 
     def __call__(self, x):
         B, H, W, C = x.shape
         qkv = ops.conv2d(self.norm(x, silu=False), self.qkv)
-        a = ops.attention(qkv.view(B, H * W, 3 * C), 1)
+        a = ops.attention(qkv.view(B, H * W, 3 * C), 1, base2=self.base2)
         return ops.conv2d(a.view(B, H, W, C), self.proj, res=x)
 
 

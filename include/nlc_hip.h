@@ -235,9 +235,12 @@ int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, float eps, con
  * (src/edm_networks.py:126-130,199-203).  The per-family q/k scaling is folded into the
  * qkv projection weights by the host, so here  out = softmax(q k^T) v  exactly.
  *   qkv: [B][T][3][H][D]   out: [B][T][H][D]   (compute dtype), softmax in f32.
+ *   logit_log2: 0 = q k^T are natural logits (e^x); 1 = the host ALSO folded log2(e) into the q (or k) projection - one more
+ *   factor in the same f64 row scale, no extra rounding - so the logits arrive in log2 units and out = softmax_2(q k^T) v with 2^x
+ *   in place of e^x: the same function of the network's weights, one multiply per score less in the kernel.
  * ---------------------------------------------------------------------------------- */
 int nlc_attention(const void* qkv, void* out, int B, int T, int H, int D,
-                  int dtype, void* stream);
+                  int dtype, int logit_log2, void* stream);
 
 /* ---- resampling on NHWC (src/unet_adm.py:107,136 ; src/unet_simple.py:48,73 ;
  *      edm_networks.py:88-93 with resample_filter [1,1]) ---- */

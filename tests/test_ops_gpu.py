@@ -319,13 +319,18 @@ ATTN_CASES = [
     dict(B=2, T=4, H=2, D=64), dict(B=1, T=1024, H=2, D=64), dict(B=1, T=80, H=1, D=128),
     dict(B=1, T=48, H=1, D=256), dict(B=1, T=70, H=1, D=512),
     # 64 channels per head, T a multiple of 256: bf16 takes the register-resident kernel (attn_d64_kernel)
-    dict(B=2, T=512, H=3, D=64), dict(B=1, T=768, H=2, D=64, spike=True),
+    dict(B=2, T=512, H=3, D=64), dict(B=1, T=768, H=2, D=64, spike=True), dict(B=1, T=512, H=2, D=64, allneg=True),
 ]
 
 
+@pytest.mark.parametrize("base2", [False, True], ids=["natural-logits", "log2-logits"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
 @pytest.mark.parametrize("case", ATTN_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_attention(case, dtype):
+def test_attention(case, dtype, base2):
+    """``base2``: the caller folded log2(e) into q (what 16-bit models do at pack time) and the kernel exponentiates with 2^x.  The
+    register-resident kernel (D = 64, T % 256 == 0, 16-bit) subtracts no running maximum while every query of a wave stays within
+    2^+-64: the `spike` case drives some waves out of that range mid-row (general path: offset, rescale of O and l) and
+    `allneg` starts a row far below it (first-tile offset), both against the plain softmax."""
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(5)
     B, T, H, D = case["B"], case["T"], case["H"], case["D"]
@@ -336,12 +341,19 @@ def test_attention(case, dtype):
         # every query (tile 9 of 12), and one query row that also spikes against them
         qkv[:, 600:603, 1] *= 6.0
         qkv[:, 17, 0] *= 4.0
+    if case.get("allneg"):
+        # every logit of some queries far below zero (~ -150 in log2 units): without a first-tile offset 2^s underflows to l = 0
+        qkv[:, :, 1, :, 0] = 6.0
+        qkv[:, 5:9, 0, :, :] = 0.0
+        qkv[:, 5:9, 0, :, 0] = -18.0
+    if base2:
+        qkv[:, :, 0] *= 1.4426950408889634      # log2(e) folded into q BEFORE the rounding to the compute dtype, as pack_conv does
     r = _rt(qkv, dtype)
     q, k, v = r[:, :, 0], r[:, :, 1], r[:, :, 2]          # [B,T,H,D]
     s = torch.einsum("bthd,bshd->bhts", q, k)
-    p = torch.softmax(s, dim=-1)
+    p = torch.softmax(s * (0.6931471805599453 if base2 else 1.0), dim=-1)      # softmax_2(s) = softmax(s ln 2)
     ref = torch.einsum("bhts,bshd->bthd", p, v).reshape(B, T, H * D)
-    got = ops.attention(qkv.reshape(B, T, 3 * H * D).to(_dev(), dtype), H)
+    got = ops.attention(qkv.reshape(B, T, 3 * H * D).to(_dev(), dtype), H, base2=base2)
     _close(got, ref, _tol(dtype) * (1 if dtype == torch.float32 else 1.5), "attention")
 
 
