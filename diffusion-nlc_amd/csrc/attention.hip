@@ -246,7 +246,10 @@ constexpr int FQ_WAVES = 8, FQ_ROWS = 256, FKV = 64;
 constexpr int F_SUB = 1;                               // 64-key tiles per stage (= per barrier); 2 measured slower (55.9 vs 51.7 us at T = 1024)
 constexpr int F_TILE = FKV * 128;                      // one K or V tile: 64 rows x 128 B
 constexpr int F_STAGE = F_SUB * F_TILE;
-constexpr int F_LDS = 4 * F_STAGE;                     // K0 K1 V0 V1 = 32 KiB
+constexpr int F_NST = 4;                               // K / V stages: tiles t+1 .. t+3 in flight while tile t computes.  With one tile of
+                                                       // prefetch every tile waited for its DMA (an L2 round trip is longer than a tile's
+                                                       // ~1.7 k cycles of work): waves parked 37 % of the time (profiles/r03_summary.md)
+constexpr int F_LDS = 2 * F_NST * F_STAGE;             // 64 KiB (two workgroups per CU)
 
 
 __device__ __forceinline__ int fk_swz(int row) { return (row >> 1) & 7; }                              // ds_read_b128 of K rows
@@ -270,7 +273,8 @@ __device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_base)
 // the exponential and half a convert, nothing else:
 //   * BASE2 (log2 e folded into the q projection at pack time, nlc_attention(logit_log2 = 1)): p = 2^s needs no multiply;
 //   * no per-tile maximum subtraction: softmax is invariant to the offset, and 2^s cannot overflow while the running maximum stays
-//     below 2^64, so the offset `moff` stays 0 (wave-uniformly) until a lane's running maximum leaves [-64, 64] log2 units - only then
+//     below 2^64 (bf16 probabilities have f32's exponent range; for f16 the window is 2^+-8), so the offset `moff` stays 0
+//     (wave-uniformly) until a lane's running maximum leaves [-64, 64] log2 units - only then
 //     does that wave take the general path (subtract, rescale O and l) for the rest of its rows; the tile maximum itself is still
 //     computed (16 v_max3), it is what detects the excursion;
 //   * the row sums l come from the matrix pipe: one more MFMA per k-step with an all-ones A operand and the same P^T fragment
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
         for (int u = 0; u < F_SUB; ++u) {
             const int64_t o = (int64_t)(tile * F_SUB + u) * FKV * tok;
             attn_glds16(ksrc + o, lds0 + stage * F_STAGE + u * F_TILE + dma_off);
-            attn_glds16(vsrc + o, lds0 + (2 + stage) * F_STAGE + u * F_TILE + dma_off);
+            attn_glds16(vsrc + o, lds0 + (F_NST + stage) * F_STAGE + u * F_TILE + dma_off);
         }
     };
 
@@ -347,20 +351,20 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
     const unsigned one2 = std::is_same<T, bf16_raw>::value ? 0x3F803F80u : 0x3C003C00u;      // two 1.0 in T
     const uint4 ones = make_uint4(one2, one2, one2, one2);
 
-    const int ntiles = Tn / (FKV * F_SUB);
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the compiler's own bookkeeping must also see the Q loads as complete HERE: otherwise it waits for them with counted
-    // vmcnt(N) inside the loop, and since it cannot see the asm DMAs those counts drain each tile's prefetch at once
+    const int ntiles = Tn / (FKV * F_SUB);               // >= 4 (dispatch: T % 256 == 0)
+    // the compiler's own bookkeeping must see the Q loads as complete BEFORE the first DMA: otherwise it waits for them with counted
+    // vmcnt(N) inside the loop, and since it cannot see the asm DMAs those counts drain the prefetch at once
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    issue(0, 0); issue(1, 1); issue(2, 2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // two pieces (K, V) per tile and wave: tile 0 landed, tiles 1, 2 may fly
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
-        const int st = t & 1;
-        if (t + 1 < ntiles) issue(t + 1, st ^ 1);        // the other stage was last read during tile t - 1 (barrier passed)
+        const int st = t & (F_NST - 1);
+        if (t + 3 < ntiles) issue(t + 3, (t + 3) & (F_NST - 1));      // that stage was last read during tile t - 1 (barrier passed)
 #pragma unroll
       for (int u = 0; u < F_SUB; ++u) {
         const char* Kt = smem + st * F_STAGE + u * F_TILE;
-        const char* Vt = smem + (2 + st) * F_STAGE + u * F_TILE;
+        const char* Vt = smem + (F_NST + st) * F_STAGE + u * F_TILE;
         // ---- S^T = K Q^T : two 32-key blocks
         f32x16_t s0, s1;
 #pragma unroll
@@ -375,9 +379,13 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
         // ---- tile maximum of the RAW scores (v_max3_f32 from inline asm: fmaxf() on an MFMA output makes hipcc insert a quieting
         // v_max(x, x) per element first).  The first maximum is plain C so that the compiler itself pads the MFMA -> VALU read
         // hazard of both accumulators; every asm statement depends on it through `tm`.
-        float tm = fmaxf(s0[0], s1[0]);
+        float tm = fmaxf(s0[0], s1[0]), tm2 = fmaxf(s0[1], s1[1]);        // two chains: a v_max3 waits for the previous one of its chain
 #pragma unroll
-        for (int r = 1; r < 16; ++r) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(s0[r]), "v"(s1[r]));
+        for (int r = 2; r < 16; r += 2) {
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(s0[r]), "v"(s1[r]));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm2) : "v"(s0[r + 1]), "v"(s1[r + 1]));
+        }
+        tm = fmaxf(tm, tm2);
         {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tm), __float_as_uint(tm), false, false);
             tm = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));      // lanes l and l ^ 32 hold the two halves of one row
@@ -385,8 +393,10 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
         const float mnew = fmaxf(mrun, BASE2 ? tm : tm * L2E);
         // an offset is (re)chosen when the running maximum leaves [-64, 64] relative to it; on the first tile also when it lies
         // far BELOW (all logits very negative: 2^s would underflow)
+        // (bf16 has f32's exponent range; an f16 probability must stay below 2^16 and well above 2^-24, so there the window is +-8)
+        constexpr float WIN = std::is_same<T, bf16_raw>::value ? 64.f : 8.f;
         const float rel = mnew - moff;
-        const bool need = rel > 64.f || (mrun < -1e29f && rel < -64.f);
+        const bool need = rel > WIN || (mrun < -1e29f && rel < -WIN);
         mrun = mnew;
         if (__builtin_amdgcn_ballot_w64(need || moff != 0.f) != 0) {
             // general path (rare): some query of this wave carries an offset - subtract it IN PLACE, then the common exponentials
@@ -439,7 +449,10 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
             }
         }
       }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // own DMA pieces of tile t + 1 landed ...
+        // own DMA pieces of tile t + 1 landed (the pieces of tiles t + 2, t + 3 - two each - may stay in flight) ...
+        if (t + 3 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // ... and everybody's are published; tile t's stage is free
     }
     // ---- finish: normalise by the row sum (every row of lacc is the same sum), store 4 consecutive channels (8 bytes) per register quad
