@@ -15,6 +15,7 @@
 // All LDS images are row-major with the 16-byte chunk index XOR-swizzled by row bits.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -242,14 +243,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
 //     row-major V tile in that same key order with two ds_read_b64_tr_b16 each;
 //   * O^T has the query on the lane as well, so the online-softmax rescale and the final 1 / l are lane-local too.
 // exp(x) is evaluated as exp2(x log2 e) with the multiply folded into one FMA per score.
-constexpr int FQ_WAVES = 8, FQ_ROWS = 256, FKV = 64;
+constexpr int FQ_ROWS = 256, FKV = 64;
+constexpr int ATTN_W = 8, ATTN_NST = 2;                // the shipped shape (chosen by measurement, see below)                 // dispatch granularity of T (every workgroup shape divides it)
 constexpr int F_SUB = 1;                               // 64-key tiles per stage (= per barrier); 2 measured slower (55.9 vs 51.7 us at T = 1024)
 constexpr int F_TILE = FKV * 128;                      // one K or V tile: 64 rows x 128 B
 constexpr int F_STAGE = F_SUB * F_TILE;
-constexpr int F_NST = 4;                               // K / V stages: tiles t+1 .. t+3 in flight while tile t computes.  With one tile of
-                                                       // prefetch every tile waited for its DMA (an L2 round trip is longer than a tile's
-                                                       // ~1.7 k cycles of work): waves parked 37 % of the time (profiles/r03_summary.md)
-constexpr int F_LDS = 2 * F_NST * F_STAGE;             // 64 KiB (two workgroups per CU)
+// Workgroup shape W (waves = 32-query blocks per workgroup; the K / V tiles are shared by them) and K / V stages NST (NST - 1 tiles
+// in flight while one computes) are template parameters: (8, 2) is round 2's kernel, measured against (8, 4), (4, 2) and (4, 4)
+// in profiles/r03_summary.md.
 
 
 __device__ __forceinline__ int fk_swz(int row) { return (row >> 1) & 7; }                              // ds_read_b128 of K rows
@@ -267,6 +268,14 @@ __device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_base)
                  : "memory");
 }
 
+// wait until all but the youngest `tiles` x TP of this wave's DMA pieces have landed (tiles <= 0: all of them)
+template <int TP> __device__ __forceinline__ void dma_wait_tiles(int tiles) {
+    if (tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TP) : "memory");
+    else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TP) : "memory");
+    else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Softmax bookkeeping, built around what bounds this kernel: at 64 channels per head a 64-key tile is 16 MFMAs (512 matrix cycles per
 // wave) against one v_exp_f32 per score (8 issue cycles each) plus whatever else runs per score, so every per-score VALU instruction
 // besides the exponential costs matrix utilisation (round 2: 11.4 VALU per MFMA, matrix pipe 28 % busy).  Per score there is now
@@ -280,8 +289,11 @@ __device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_base)
 //   * the row sums l come from the matrix pipe: one more MFMA per k-step with an all-ones A operand and the same P^T fragment
 //     (every row of the result is sum_k P[k][q]; only register 0 is kept consistent), instead of 32 adds per tile - and they sum
 //     the ROUNDED probabilities the PV product uses.
-template <typename T, bool BASE2>
-__global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
+template <typename T, bool BASE2, int W, int NST>
+__global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
+    constexpr int F_NST = NST;
+    constexpr int WG_ROWS = W * 32;                        // queries per workgroup
+    constexpr int PP = 8 / W;                              // DMA pieces (8 rows x 128 B) of K, and of V, per wave and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,14 +302,14 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
     // XCD-aware block order: the query blocks of one (batch, head) read the same K / V, so they should run on the same
     // XCD (its L2 then serves all but the first read).  Workgroup ids are dealt round-robin over the 8 XCDs; XCD x
     // (= id & 7) takes a contiguous chunk of the [pair][query block] list (bijective for any block count).
-    const int nqb = Tn / FQ_ROWS, nblk = gridDim.x;
+    const int nqb = Tn / WG_ROWS, nblk = gridDim.x;
     int lin;
     {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, cq = nblk >> 3, cr = nblk & 7;
         lin = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
     }
     const int pair = lin / nqb, qblk = lin - pair * nqb;
-    const int b = pair / H, hd = pair - b * H, q0 = qblk * FQ_ROWS + wave * 32;
+    const int b = pair / H, hd = pair - b * H, q0 = qblk * WG_ROWS + wave * 32;
     const int64_t tok = (int64_t)3 * H * 64;            // elements between consecutive tokens
     const T* qb = qkv + (int64_t)b * Tn * tok + (int64_t)hd * 64;
     const T* kb = qb + (int64_t)H * 64;
@@ -320,8 +332,11 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
 #pragma unroll
         for (int u = 0; u < F_SUB; ++u) {
             const int64_t o = (int64_t)(tile * F_SUB + u) * FKV * tok;
-            attn_glds16(ksrc + o, lds0 + stage * F_STAGE + u * F_TILE + dma_off);
-            attn_glds16(vsrc + o, lds0 + (F_NST + stage) * F_STAGE + u * F_TILE + dma_off);
+#pragma unroll
+            for (int j = 0; j < PP; ++j) {                 // rows drow + 8 W j (same swizzle: it ignores bit 5 and above of the row)
+                attn_glds16(ksrc + o + (int64_t)j * 8 * W * tok, lds0 + stage * F_STAGE + u * F_TILE + dma_off + j * W * 1024);
+                attn_glds16(vsrc + o + (int64_t)j * 8 * W * tok, lds0 + (F_NST + stage) * F_STAGE + u * F_TILE + dma_off + j * W * 1024);
+            }
         }
     };
 
@@ -355,12 +370,15 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
     // the compiler's own bookkeeping must see the Q loads as complete BEFORE the first DMA: otherwise it waits for them with counted
     // vmcnt(N) inside the loop, and since it cannot see the asm DMAs those counts drain the prefetch at once
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
-    issue(0, 0); issue(1, 1); issue(2, 2);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // two pieces (K, V) per tile and wave: tile 0 landed, tiles 1, 2 may fly
+    constexpr int DEPTH = F_NST - 1;                     // tiles in flight beyond the one being computed
+    constexpr int TP = 2 * PP;                           // DMA pieces per wave and tile (K and V)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d, d);
+    dma_wait_tiles<TP>(DEPTH - 1);                       // tile 0 landed, the others may fly
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int st = t & (F_NST - 1);
-        if (t + 3 < ntiles) issue(t + 3, (t + 3) & (F_NST - 1));      // that stage was last read during tile t - 1 (barrier passed)
+        if (t + DEPTH < ntiles) issue(t + DEPTH, (t + DEPTH) & (F_NST - 1));      // that stage was last read during tile t - 1 (barrier passed)
 #pragma unroll
       for (int u = 0; u < F_SUB; ++u) {
         const char* Kt = smem + st * F_STAGE + u * F_TILE;
@@ -449,10 +467,8 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
             }
         }
       }
-        // own DMA pieces of tile t + 1 landed (the pieces of tiles t + 2, t + 3 - two each - may stay in flight) ...
-        if (t + 3 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // own DMA pieces of tile t + 1 landed (the pieces of later tiles may stay in flight) ...
+        dma_wait_tiles<TP>(min(DEPTH, ntiles - 1 - t) - 1);
         __syncthreads();                                       // ... and everybody's are published; tile t's stage is free
     }
     // ---- finish: normalise by the row sum (every row of lacc is the same sum), store 4 consecutive channels (8 bytes) per register quad
@@ -469,15 +485,28 @@ __global__ __launch_bounds__(FQ_WAVES * 64, 2) void attn_d64_kernel(const T* __r
         }
 }
 
-template <typename T, bool BASE2>
-int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
+template <typename T, bool BASE2, int W, int NST>
+int launch_d64v(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
+    constexpr int LDS = 2 * NST * F_STAGE;
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel<T, BASE2>), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel<T, BASE2, W, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    hipLaunchKernelGGL((attn_d64_kernel<T, BASE2>), dim3((Tn / FQ_ROWS) * H * B), dim3(FQ_WAVES * 64), F_LDS, st, (const T*)qkv, (T*)out, Tn, H);
+    hipLaunchKernelGGL((attn_d64_kernel<T, BASE2, W, NST>), dim3((Tn / (W * 32)) * H * B), dim3(W * 64), LDS, st, (const T*)qkv, (T*)out, Tn, H);
     NLC_CHECK_LAUNCH("nlc_attention(d64)");
     return NLC_OK;
+}
+
+template <typename T, bool BASE2>
+int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
+#ifdef NLC_ATTN_VARIANTS                                  /* diagnostic build (tools/variant.sh attention "-DNLC_ATTN_VARIANTS"): A/B of the shapes */
+    static const char* v = getenv("NLC_ATTN_VARIANT");
+    if (v && v[0] == 'a') return launch_d64v<T, BASE2, 8, 2>(qkv, out, B, Tn, H, st);
+    if (v && v[0] == 'b') return launch_d64v<T, BASE2, 8, 4>(qkv, out, B, Tn, H, st);
+    if (v && v[0] == 'c') return launch_d64v<T, BASE2, 4, 2>(qkv, out, B, Tn, H, st);
+    if (v && v[0] == 'd') return launch_d64v<T, BASE2, 4, 4>(qkv, out, B, Tn, H, st);
+#endif
+    return launch_d64v<T, BASE2, ATTN_W, ATTN_NST>(qkv, out, B, Tn, H, st);
 }
 
 template <typename T, int D>
