@@ -249,8 +249,9 @@ constexpr int F_SUB = 1;                               // 64-key tiles per stage
 constexpr int F_TILE = FKV * 128;                      // one K or V tile: 64 rows x 128 B
 constexpr int F_STAGE = F_SUB * F_TILE;
 // Workgroup shape W (waves = 32-query blocks per workgroup; the K / V tiles are shared by them) and K / V stages NST (NST - 1 tiles
-// in flight while one computes) are template parameters: (8, 2) is round 2's kernel, measured against (8, 4), (4, 2) and (4, 4)
-// in profiles/r03_summary.md.
+// in flight while one computes) are template parameters: (8, 2) ships; (8, 4), (4, 2), (4, 4) and a software-pipelined form
+// (experiments/attention_pipelined.inc) exist only in the diagnostic build -DNLC_ATTN_VARIANTS and were measured against it
+// (profiles/r03_summary.md: all within +-4 % or slower - neither DMA depth nor barrier lockstep nor the VALU count bounds it).
 
 
 __device__ __forceinline__ int fk_swz(int row) { return (row >> 1) & 7; }                              // ds_read_b128 of K rows
@@ -486,266 +487,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------
-// Software-pipelined form of the kernel above (same fragments, same softmax bookkeeping).  Counters of the straight-line form
-// (profiles/r03_summary.md): halving its VALU work, deepening its DMA prefetch and un-synchronising its waves (4-wave workgroups)
-// each changed nothing - every wave walks KQ^T -> maximum -> exponentials -> PV one after the other, so the matrix pipe idles through
-// each wave's VALU phase and the waves of a SIMD do not interleave enough to hide that.  Here a wave has THREE tiles in flight and
-// every iteration t issues, as one straight-line block,
-//       the 8 MFMAs of S(t+1) = K(t+1) Q^T  and  the 12 MFMAs of O += V(t-1)^T P(t-1)^T, l += 1^T P(t-1)^T
-//   beside the exponentials and converts of P(t) = 2^(S(t) - offset),
-// followed by the tile maximum of S(t+1) and the (rare) offset decision for it.  The fast / general choice for tile t was made one
-// iteration earlier, so the block has no branch inside.  Per iteration and wave: 20 MFMAs (640 matrix cycles) beside ~50 VALU
-// instructions, then ~25 more.  K runs three tiles ahead (needed one iteration earlier than V), V two; four LDS stages each.
-template <typename T, bool BASE2, int W>
-__global__ __launch_bounds__(W * 64, 2) void attn_d64p_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
-    constexpr int NSTG = 4;
-    constexpr int WG_ROWS = W * 32;
-    constexpr int PP = 8 / W;                              // DMA pieces of K (and of V) per wave and tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane & 31, h = lane >> 5;
-    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
-    const int nqb = Tn / WG_ROWS, nblk = gridDim.x;
-    int lin;
-    {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, cq = nblk >> 3, cr = nblk & 7;
-        lin = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
-    }
-    const int pair = lin / nqb, qblk = lin - pair * nqb;
-    const int b = pair / H, hd = pair - b * H, q0 = qblk * WG_ROWS + wave * 32;
-    const int64_t tok = (int64_t)3 * H * 64;
-    const T* qb = qkv + (int64_t)b * Tn * tok + (int64_t)hd * 64;
-    const T* kb = qb + (int64_t)H * 64;
-    const T* vb = qb + (int64_t)2 * H * 64;
-    uint4 qf[4];
-    {
-        const T* qp = qb + (int64_t)(q0 + q) * tok + h * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16);
-    }
-    const int drow = wave * 8 + (lane >> 3), dslot = lane & 7;
-    const T* ksrc = kb + (int64_t)drow * tok + ((dslot ^ fk_swz(drow)) << 3);
-    const T* vsrc = vb + (int64_t)drow * tok + ((dslot ^ fv_swz(drow)) << 3);
-    const unsigned dma_off = (unsigned)wave * 1024u;
-    auto issue_k = [&](int tile) {
-        const int64_t o = (int64_t)tile * FKV * tok;
-#pragma unroll
-        for (int j = 0; j < PP; ++j) attn_glds16(ksrc + o + (int64_t)j * 8 * W * tok, lds0 + (tile & 3) * F_TILE + dma_off + j * W * 1024);
-    };
-    auto issue_v = [&](int tile) {
-        const int64_t o = (int64_t)tile * FKV * tok;
-#pragma unroll
-        for (int j = 0; j < PP; ++j) attn_glds16(vsrc + o + (int64_t)j * 8 * W * tok, lds0 + (NSTG + (tile & 3)) * F_TILE + dma_off + j * W * 1024);
-    };
-    int koff[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) koff[s] = q * 128 + (((2 * s + h) ^ fk_swz(q)) << 4);
-    const int cb = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
-    auto voff = [&](int ks, int db, int second) {
-        const int row = 16 * ks + 4 * h + qq + 8 * second;
-        const int colb = (db * 32 + cb * 16 + 4 * pp) * 2;
-        return row * 128 + ((((colb >> 4)) ^ fv_swz(row)) << 4) + (colb & 15);
-    };
-    // voff(ks, db, second) = voff(0, db, 0) + (16 ks + 8 second) * 128: the row swizzle fv_swz only looks at row bits 0-2, which the
-    // 16 ks + 8 second part never touches - two registers and compile-time offsets instead of sixteen registers
-    const int vbase[2] = {voff(0, 0, 0), voff(0, 1, 0)};
-
-    f32x16_t o0, o1, lacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; lacc[r] = 0.f; }
-    float mrun = -1e30f, moff = 0.f, alpha_pend = 1.f;  // running maximum, current offset (log2 units), rescale owed to O and l
-    uint4 pf[4];                                         // P^T fragments of the tile whose PV product is next
-    bool general = false;                                // wave-uniform: some query of this wave carries an offset
-    constexpr float L2E = 1.44269504088896340736f;
-    constexpr float WIN = std::is_same<T, bf16_raw>::value ? 64.f : 8.f;
-    const unsigned one2 = std::is_same<T, bf16_raw>::value ? 0x3F803F80u : 0x3C003C00u;
-    const uint4 ones = make_uint4(one2, one2, one2, one2);
-
-    // S^T of one tile: 8 MFMAs from K stage (tile & 3)
-    auto kq = [&](int tile, f32x16_t& x0, f32x16_t& x1) {
-        const char* Kt = smem + (tile & 3) * F_TILE;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { x0[r] = 0.f; x1[r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint4 ka = *reinterpret_cast<const uint4*>(Kt + koff[s]);
-            const uint4 kc = *reinterpret_cast<const uint4*>(Kt + koff[s] + 4096);
-            x0 = Mfma16<T>::run32(ka, qf[s], x0);
-            x1 = Mfma16<T>::run32(kc, qf[s], x1);
-        }
-    };
-    // tile maximum of raw scores + offset decision for that tile (see attn_d64_kernel): updates mrun / moff / alpha_pend / general
-    auto decide = [&](const f32x16_t& x0, const f32x16_t& x1) {
-        float tm = fmaxf(x0[0], x1[0]), tm2 = fmaxf(x0[1], x1[1]);
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(x0[r]), "v"(x1[r]));
-            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm2) : "v"(x0[r + 1]), "v"(x1[r + 1]));
-        }
-        tm = fmaxf(tm, tm2);
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tm), __float_as_uint(tm), false, false);
-            tm = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        const float mnew = fmaxf(mrun, BASE2 ? tm : tm * L2E);
-        const float rel = mnew - moff;
-        const bool first = mrun < -1e29f;
-        const bool need = rel > WIN || (first && rel < -WIN);
-        mrun = mnew;
-        if (__builtin_amdgcn_ballot_w64(need) != 0) {
-            const float mo = need ? mnew : moff;
-            // nothing is accumulated before the first tile; afterwards need implies mo > moff, so the factor is < 1
-            alpha_pend *= first ? 1.f : __builtin_amdgcn_exp2f(moff - mo);
-            moff = mo;
-        }
-        general = __builtin_amdgcn_ballot_w64(moff != 0.f) != 0;
-    };
-    // P = 2^(S - offset), in place
-    auto exps = [&](f32x16_t& x0, f32x16_t& x1, auto general_c) {
-        constexpr bool GEN = decltype(general_c)::value;
-        const float sub = BASE2 ? moff : moff * (1.0f / L2E);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a0 = GEN ? x0[r] - sub : x0[r], a1 = GEN ? x1[r] - sub : x1[r];
-            x0[r] = __builtin_amdgcn_exp2f(BASE2 ? a0 : a0 * L2E);
-            x1[r] = __builtin_amdgcn_exp2f(BASE2 ? a1 : a1 * L2E);
-        }
-    };
-    // ... packed to T as the four k-step fragments of P^T (registers 8 s .. 8 s + 7 of a 32-key block are k-step s)
-    auto pack = [&](const f32x16_t& x0, const f32x16_t& x1) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (std::is_same<T, bf16_raw>::value) {
-                bf16x8_t pb;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)((ks < 2 ? x0 : x1)[(ks & 1) * 8 + j]);
-                pf[ks] = __builtin_bit_cast(uint4, pb);
-            } else {
-                f16x8_t ph;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ph[j] = (f16_raw)((ks < 2 ? x0 : x1)[(ks & 1) * 8 + j]);
-                pf[ks] = __builtin_bit_cast(uint4, ph);
-            }
-        }
-    };
-    auto pv = [&](int tile) {
-        const char* Vt = smem + (NSTG + (tile & 3)) * F_TILE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            lacc = Mfma16<T>::run32(ones, pf[ks], lacc);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vt + vbase[db] + (16 * ks) * 128));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vt + vbase[db] + (16 * ks + 8) * 128));
-                uint4 va;
-                va.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
-                va.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
-                va.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
-                va.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                if (db == 0) o0 = Mfma16<T>::run32(va, pf[ks], o0);
-                else o1 = Mfma16<T>::run32(va, pf[ks], o1);
-            }
-        }
-    };
-    // the rescale a new offset owes to O and l: applied between PV(t-1) and PV(t)
-    auto settle = [&]() {
-        if (__builtin_amdgcn_ballot_w64(alpha_pend != 1.f) != 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha_pend; o1[r] *= alpha_pend; }
-            lacc[0] *= alpha_pend;
-            alpha_pend = 1.f;
-        }
-    };
-
-    const int ntiles = Tn / FKV;                          // >= 4, a multiple of 4 (dispatch: T % 256 == 0)
-    constexpr int TP = PP;                               // pieces per wave of ONE issue group (K or V of one tile)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // the Q loads are complete before the first DMA (see attn_d64_kernel)
-    // issue order (per wave): K0 K1 V0 K2 V1 | iteration t: K(t+3) V(t+2).  Iteration t reads K(t+1) and V(t-1).
-    issue_k(0); issue_k(1); issue_v(0); issue_k(2); issue_v(1);
-    dma_wait_tiles<TP>(4);                               // K0 landed
-    __syncthreads();
-    f32x16_t sa0, sa1, sb0, sb1;
-    kq(0, sa0, sa1);
-    decide(sa0, sa1);
-    dma_wait_tiles<TP>(3);                               // K1 landed (V0, K2, V1 may fly)
-    __syncthreads();
-
-    // one iteration: PV of tile t-1 (fragments in pf) beside the exponentials of tile t (scores `c`), then pf <- P(t) beside the
-    // 8 MFMAs of S(t+1) (into `n`)
-    auto iter = [&](int t, f32x16_t& c0, f32x16_t& c1, f32x16_t& n0, f32x16_t& n1, auto kq_c, auto pv_c) {
-        constexpr bool DO_KQ = decltype(kq_c)::value, DO_PV = decltype(pv_c)::value;
-        if (t + 3 < ntiles) issue_k(t + 3);              // stage of K(t-1): last read in iteration t-2
-        if (t + 2 < ntiles) issue_v(t + 2);              // stage of V(t-2): last read in iteration t-1
-        // ONE straight-line block per variant (the fast / general choice for tile t was made an iteration ago)
-        auto body = [&](auto gen_c) {
-            if constexpr (DO_PV) pv(t - 1);              // O, l and P(t-1) all relative to the offset of tile t-1
-            exps(c0, c1, gen_c);
-            pack(c0, c1);                                // overwrites pf: after the PV MFMAs that read it have issued
-            if constexpr (DO_KQ) kq(t + 1, n0, n1);
-            if constexpr (DO_KQ && DO_PV) {
-                // issue order for the in-order wave: every MFMA (8 issue cycles, 32 in the pipe) is followed by exponentials /
-                // converts that issue while it runs (left alone the backend emits the exponentials as one burst)
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {                                      // PV(t-1), l: 12 MFMAs beside the 32 exponentials
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 3, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {                                      // S(t+1): 8 MFMAs beside the 16 converts
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
-            }
-        };
-        if (general) body(std::true_type{}); else body(std::false_type{});
-        if constexpr (DO_PV) settle();                   // ... and only now O, l move to the offset chosen for tile t
-        if constexpr (DO_KQ) decide(n0, n1);             // offset / path for tile t+1 (may add to alpha_pend)
-        // K(t+2) and V(t) must have landed before the next iteration; younger groups may fly: V(t+1), K(t+3), V(t+2)
-        dma_wait_tiles<TP>(t + 3 < ntiles ? 3 : 0);
-        __syncthreads();
-    };
-    using Y = std::true_type; using N = std::false_type;
-    iter(0, sa0, sa1, sb0, sb1, Y{}, N{});                                    // P(0) | S(1)
-    for (int t = 1; t + 1 < ntiles; t += 2) {                                  // t = 1 .. ntiles - 2 in pairs (ntiles is even)
-        iter(t, sb0, sb1, sa0, sa1, Y{}, Y{});                                 // PV(t-1) | P(t) | S(t+1)
-        iter(t + 1, sa0, sa1, sb0, sb1, Y{}, Y{});
-    }
-    iter(ntiles - 1, sb0, sb1, sa0, sa1, N{}, Y{});                           // PV(n-2) | P(n-1), then O, l at the last offset
-    pv(ntiles - 1);
-
-    const float inv = 1.0f / lacc[0];
-    T* op = out + ((int64_t)b * Tn + q0 + q) * ((int64_t)H * 64) + (int64_t)hd * 64 + 4 * h;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x16_t& o = db ? o1 : o0;
-            const float ov[8] = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv, 0.f, 0.f, 0.f, 0.f};
-            const uint4 pk = f32_to_chunk<T>(ov);
-            *reinterpret_cast<uint2*>(op + db * 32 + 8 * g) = make_uint2(pk.x, pk.y);
-        }
-}
-
-template <typename T, bool BASE2, int W>
-int launch_d64p(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
-    constexpr int LDS = 2 * 4 * F_TILE;                  // four K and four V stages: 64 KiB
-    static DeviceOnce once;
-    (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64p_kernel<T, BASE2, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    });
-    hipLaunchKernelGGL((attn_d64p_kernel<T, BASE2, W>), dim3((Tn / (W * 32)) * H * B), dim3(W * 64), LDS, st, (const T*)qkv, (T*)out, Tn, H);
-    NLC_CHECK_LAUNCH("nlc_attention(d64p)");
-    return NLC_OK;
-}
+#ifdef NLC_ATTN_VARIANTS
+#include "experiments/attention_pipelined.inc"
+#endif
 
 template <typename T, bool BASE2, int W, int NST>
 int launch_d64v(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
@@ -767,7 +511,7 @@ int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st)
     if (v && v[0] == 'b') return launch_d64v<T, BASE2, 8, 4>(qkv, out, B, Tn, H, st);
     if (v && v[0] == 'c') return launch_d64v<T, BASE2, 4, 2>(qkv, out, B, Tn, H, st);
     if (v && v[0] == 'd') return launch_d64v<T, BASE2, 4, 4>(qkv, out, B, Tn, H, st);
-    if (v && v[0] == 'p') return launch_d64p<T, BASE2, 8>(qkv, out, B, Tn, H, st);
+    if (v && v[0] == 'p') return launch_d64p<T, BASE2, 8>(qkv, out, B, Tn, H, st);      // experiments/attention_pipelined.inc
     if (v && v[0] == 'q') return launch_d64p<T, BASE2, 4>(qkv, out, B, Tn, H, st);
 #endif
     return launch_d64v<T, BASE2, ATTN_W, ATTN_NST>(qkv, out, B, Tn, H, st);
