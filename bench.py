@@ -518,11 +518,12 @@ def roofline_leg(wl, x, dtype, args):
            "share_of_step": tot_ms * 1e-3 / wall, "measured": "HIP events around every conv launch of one extra (untimed) step"}
     # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
     # tagged with the hash of the kernel sources they were taken on
-    tpath = ROOT / "profiles" / "r02_pmc_traffic.json"
-    if wl.name == "adm256" and wl.res == 256 and args.dtype == "bf16" and tpath.exists():
+    tfiles = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))          # the newest round's profile
+    tpath = tfiles[-1] if tfiles else None
+    if wl.name == "adm256" and wl.res == 256 and args.dtype == "bf16" and tpath is not None:
         tj = json.loads(tpath.read_text())
         out["traffic"] = tj.get("conv2d_bytes_per_launch")
-        out["traffic_source"] = {"file": "profiles/r02_pmc_traffic.json", "csrc_sha16": tj.get("csrc_sha16"),
+        out["traffic_source"] = {"file": f"profiles/{tpath.name}", "csrc_sha16": tj.get("csrc_sha16"),
                                  "matches_this_build": tj.get("csrc_sha16") == csrc_sha16()}
         dom = [(m, f) for m, f, shp in sel if shp[:4] == (wl.batch * 256 * 256, 256, 9, 256) and shp[5] == 0]
         if dom and "dominant" in tj:

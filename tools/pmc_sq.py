@@ -32,6 +32,9 @@ def read(path, sub):
 def main():
     a, b = sys.argv[1:3]
     sub = sys.argv[3] if len(sys.argv) > 3 else "conv_halo_kernel"
+    label = sys.argv[4] if len(sys.argv) > 4 else sub + ", 256->256 3x3 @256^2, B=16: 1.237 TFLOP per launch"
+    how = sys.argv[5] if len(sys.argv) > 5 else ("rocprofv3 --kernel-trace --pmc <8 SQ counters (+ GRBM_GUI_ACTIVE)> -- python3 tools/conv_bench.py --only 0 "
+                                                 "--reps 2 --rounds 1 (two passes, tools/profile_round.sh)")
     ca, us_a, na = read(a, sub)
     cb, us_b, nb = read(b, sub)
     c = {**ca, **cb}
@@ -45,9 +48,9 @@ def main():
         "wave_time_issuing (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
         "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT", 0.0),
     }
-    print(json.dumps({"kernel": sub + ", 256->256 3x3 @256^2, B=16: 1.237 TFLOP per launch", "launch_us_under_profiler": us_a,
+    print(json.dumps({"kernel": label, "launch_us_under_profiler": us_a,
                       "dispatches_profiled": [na, nb], "counters_per_launch": c, "derived": der,
-                      "how": "rocprofv3 --kernel-trace --pmc <8 SQ counters (+ GRBM_GUI_ACTIVE)> -- python3 tools/conv_bench.py --only 0 --reps 2 --rounds 1 (two passes, tools/profile_round.sh)"},
+                      "how": how},
                      indent=1))
 
 
