@@ -560,12 +560,13 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
         else { using TG = float; __VA_ARGS__; }                          \
     } while (0)
 
-// threads per group of gn_finalize_chunks_kernel: ~16 (chunk, partial) items per thread, a power of two in [8, 256]
+// threads per group of gn_finalize_chunks_kernel: ~4 (chunk, partial) items per thread (each a dependent-latency load), a power of
+// two in [8, 256]
 static int finalize_tpg(int gs, int P0, int P1, int C0, int C1) {
     const int64_t items = (int64_t)(gs / 4 > 0 ? gs / 4 : 1) * (P0 > P1 ? P0 : P1);
     (void)C0; (void)C1;
     int tpg = 8;
-    while (tpg < NT && (int64_t)tpg * 16 < items) tpg *= 2;
+    while (tpg < NT && (int64_t)tpg * 4 < items) tpg *= 2;
     return tpg;
 }
 #define FIN_GRID(G, B, tpg) dim3(cdiv((G), NT / (tpg)), (B))
