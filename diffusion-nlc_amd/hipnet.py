@@ -66,7 +66,8 @@ def _graphable(fn):
     t and input scale): it is captured once per (entry point, shapes, dtypes, options) on a side stream into a private
     memory pool and then replayed with ONE hipGraphLaunch.  Inputs are copied into the capture's static buffers unless
     the caller already passes those; the returned tensors are the capture's static outputs - valid until the next
-    replay of the same graph (the sampling loops consume them before they evaluate the network again)."""
+    replay of the same graph (the sampling loops consume them before they evaluate the network again): a caller that keeps
+    an ``eps`` / ``feat`` tensor across another evaluation of the same entry point must ``clone()`` it."""
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
         if not self.use_graphs or torch.cuda.is_current_stream_capturing():
@@ -97,14 +98,22 @@ class HipModule:
         with torch.cuda.device(self.device):
             if ent is None:
                 self.plan()
-                fn(self, *args, **kwargs)                        # eager once: every kernel's one-time launch setup happens here, and
-                                                                 # the conv / GroupNorm workspaces reach their final size OUTSIDE the capture
+                # Warm-up AND capture run on one side stream owned by this module: every kernel's one-time launch setup happens in the
+                # eager warm-up, and so do the allocations of the per-stream conv / GroupNorm workspaces (ops._conv_ws / _gn_ws are
+                # keyed by stream) - they come from the ordinary pool, zeroed counters included, and are merely REFERENCED by the
+                # capture instead of being born inside a graph's private pool.
+                cs = self.__dict__.get("_capture_stream")
+                if cs is None:
+                    cs = self.__dict__["_capture_stream"] = torch.cuda.Stream(device=self.device)
                 static = [a.clone() if torch.is_tensor(a) else a for a in items]
                 s_args = static[:len(args)]
                 s_kwargs = dict(zip(sorted(kwargs), static[len(args):]))
+                cs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cs):
+                    fn(self, *s_args, **s_kwargs)
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=cs):
                     out = fn(self, *s_args, **s_kwargs)
                 ent = cache[key] = (g, static, out)
             g, static, out = ent

@@ -278,7 +278,10 @@ def _launch_conv(lib, d: ConvDesc, dt: torch.dtype) -> None:
 
 
 def reset_conv_workspaces() -> None:
-    """Forget every split-K workspace (they are re-allocated zeroed on demand).  Called after a failed nlc_conv2d."""
+    """Forget every split-K workspace (they are re-allocated zeroed on demand).  Called after a failed nlc_conv2d.  The old buffers
+    stay allocated (captured hipGraphs may reference them) - a graph that replays a poisoned buffer must be re-captured
+    (HipModule.drop_graphs)."""
+    _ws_retired.extend(_conv_ws.values())
     _conv_ws.clear()
 
 
@@ -308,6 +311,7 @@ def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 
 _gn_ws = {}
 _conv_ws = {}
+_ws_retired = []             # outgrown workspaces stay allocated (hipGraphs captured earlier keep their addresses)
 FUSED_GN_STATS = True        # groupnorm() uses statistics emitted by the producing conv2d() when they are attached
 
 
@@ -317,6 +321,8 @@ def _conv_workspace(device, nbytes: int) -> torch.Tensor:
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)          # a captured hipGraph may still reference the smaller buffer: never hand it back
         ws = torch.zeros(nbytes // 4 + 1, device=device, dtype=torch.float32)
         _conv_ws[key] = ws
     return ws
@@ -326,6 +332,8 @@ def _gn_workspace(device, nbytes: int) -> torch.Tensor:
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)
         ws = torch.empty(max(nbytes // 4 + 1, 1 << 16), device=device, dtype=torch.float32)
         _gn_ws[key] = ws
     return ws
