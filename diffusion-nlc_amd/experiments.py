@@ -490,7 +490,8 @@ class ExperimentDiffusion:
         (src/experiments.py:665-681): the regression target  dist_real = ||new_noise|| / sqrt(dim)  (B,1,1,1), the noised
         batch  noisy_x = scheduler.diffusion(batch_x, t, new_noise)  and the frozen eps model's features
         ``feat = cat_i model.encode(noisy_x[i : i + microbatch], t[i : i + microbatch])`` (NCHW f32).  The sigma net's own
-        forward / backward / DDP exchange stay with the training framework (out of scope: SURVEY.md §8 f-4)."""
+        forward / backward / optimizer stay with the training framework; the cross-GPU half of :645-652 is
+        ``sync_sigma_parameters`` / ``average_sigma_gradients`` below."""
         dev = self.device
         batch_x = batch_x.to(dev, torch.float32).contiguous()
         new_noise = new_noise.to(dev, torch.float32).contiguous()
@@ -502,8 +503,26 @@ class ExperimentDiffusion:
         return torch.cat(feats), dist_real, noisy_x
 
 
+    # the two collectives DistributedDataParallel(sigma_model, bucket_cap_mb=128, broadcast_buffers=False) contributes to
+    # ImageExperiment.train (src/experiments.py:645-652,682-686), for a training framework that keeps the sigma net's trainable
+    # copy as ordinary tensors (one process per GPU, shard.init_from_env)
+    @staticmethod
+    def sync_sigma_parameters(params, src=0, bucket_mb=128):
+        """DDP construction: rank ``src``'s parameters to every rank, in place, in ``bucket_mb`` buckets."""
+        from . import shard
+        shard.broadcast_parameters_(params, src=src, bucket_bytes=bucket_mb << 20)
+
+    @staticmethod
+    def average_sigma_gradients(grads, bucket_mb=128):
+        """DDP's gradient exchange: mean over ranks, in place, one all-reduce per ``bucket_mb`` bucket.  (Upstream runs every
+        forward under ``no_sync()`` (:682-686), so its own loop never reaches this; a loop that wants synchronous data-parallel
+        training calls it between backward and the optimizer step.)"""
+        from . import shard
+        shard.allreduce_mean_(grads, bucket_bytes=bucket_mb << 20)
+
+
 class ImageExperiment(ExperimentDiffusion):
-    """src/experiments.py:553-560 (sampling only; training of the sigma net is out of scope)."""
+    """src/experiments.py:553-560 (sampling; of the sigma net's training the frozen-encoder half and the cross-GPU exchange)."""
 
     def __init__(self, model, scheduler, batch_size=64, data_shape=(3, 32, 32), seed=0, device="cuda:0", save_folder="./",
                  dist_train=False, time_shift=0):

@@ -77,6 +77,55 @@ def replay_draws(gen: torch.Generator, shape: Sequence[int], n: int) -> None:
         torch.randn(tuple(shape), generator=gen)
 
 
+# ---- the exchange half of the sigma-net training (src/experiments.py:645-652) ------------------------------------------
+# The reference wraps the sigma net in DistributedDataParallel(bucket_cap_mb=128, broadcast_buffers=False): constructing it
+# broadcasts rank 0's parameters to every rank, and a backward pass outside `no_sync()` averages the gradients in 128 MB buckets.
+# (Its training loop happens to run every forward under `no_sync()` (:682-686), so upstream only the initial broadcast ever
+# crosses GPUs.)  Both collectives, on flat buckets, over whatever backend the job runs (RCCL over xGMI: ring all-reduce is
+# per-link bound at ~153 GB/s, so few large buckets - the 61.4 M-parameter ADM sigma net is two of them).
+def _buckets(tensors, bucket_bytes: int):
+    cur, size = [], 0
+    for t in tensors:
+        n = t.numel() * t.element_size()
+        if cur and (size + n > bucket_bytes or t.dtype != cur[0].dtype or t.device != cur[0].device):
+            yield cur
+            cur, size = [], 0
+        cur.append(t)
+        size += n
+    if cur:
+        yield cur
+
+
+def broadcast_parameters_(tensors, src: int = 0, bucket_bytes: int = 128 << 20) -> None:
+    """In place: every rank's ``tensors`` become rank ``src``'s (DDP's construction-time parameter sync), bucket by bucket."""
+    world, _ = world_rank()
+    if world == 1:
+        return
+    for b in _buckets(list(tensors), bucket_bytes):
+        flat = torch.cat([t.reshape(-1) for t in b])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in b:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
+def allreduce_mean_(tensors, bucket_bytes: int = 128 << 20) -> None:
+    """In place: every rank's ``tensors`` (gradients) become the mean over ranks (what DDP's backward hook does), bucket by
+    bucket, one all-reduce each."""
+    world, _ = world_rank()
+    if world == 1:
+        return
+    for b in _buckets(list(tensors), bucket_bytes):
+        flat = torch.cat([t.reshape(-1) for t in b])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+        off = 0
+        for t in b:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
 def gather_samples(local: torch.Tensor, n_batches: int, world: int, rank: int) -> torch.Tensor:
     """All-gather per-rank results [n_local, B, ...] and restore global batch order -> [n_batches, B, ...].
 

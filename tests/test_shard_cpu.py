@@ -199,3 +199,49 @@ def test_evaluate_edm_two_ranks_equal_single_process():
         assert p.exitcode == 0
     assert order1 == order2 == list(range(5))
     assert both.shape == (10, 3, 4, 4) and (both == single).all()
+
+
+# ---- the exchange half of the sigma-net training: DDP's construction-time parameter broadcast and its bucketed
+#      gradient averaging, as ImageExperiment.sync_sigma_parameters / average_sigma_gradients -------------------------------------------
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    shard.init_from_env("gloo")
+    from diffusion_nlc_amd.experiments import ImageExperiment
+    g = torch.Generator().manual_seed(100 + rank)                     # every rank starts from DIFFERENT values
+    shapes = [(128, 1024, 3, 3), (128,), (7, 5), (1,), (300, 300)]
+    params = [torch.randn(s, generator=g) for s in shapes]
+    grads = [torch.randn(s, generator=g) * (rank + 1) for s in shapes]
+    ImageExperiment.sync_sigma_parameters(params, src=0, bucket_mb=1)           # 1 MB buckets: the 4.7 MB tensor is a bucket of its own
+    ImageExperiment.average_sigma_gradients(grads, bucket_mb=1)
+    q.put((rank, [p.numpy() for p in params], [x.numpy() for x in grads]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sigma_training_exchange_two_ranks():
+    """After sync_sigma_parameters every rank holds rank 0's parameters; after average_sigma_gradients every rank holds the mean of
+    the two ranks' gradients (src/experiments.py:645-652: DistributedDataParallel(bucket_cap_mb=128) on the sigma net)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, params, grads = q.get(timeout=180)
+        got[r] = (params, grads)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    shapes = [(128, 1024, 3, 3), (128,), (7, 5), (1,), (300, 300)]
+    g0, g1 = torch.Generator().manual_seed(100), torch.Generator().manual_seed(101)
+    p0 = [torch.randn(s, generator=g0) for s in shapes]
+    gr0 = [torch.randn(s, generator=g0) for s in shapes]
+    _ = [torch.randn(s, generator=g1) for s in shapes]
+    gr1 = [torch.randn(s, generator=g1) * 2 for s in shapes]
+    for r in range(2):
+        for a, b in zip(got[r][0], p0):
+            assert torch.equal(torch.from_numpy(a), b)
+        for a, x, y in zip(got[r][1], gr0, gr1):
+            assert torch.allclose(torch.from_numpy(a), (x + y) / 2, rtol=0, atol=1e-6)
