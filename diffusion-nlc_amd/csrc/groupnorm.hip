@@ -40,9 +40,6 @@ struct GNParams {
     char* out;
     double* ws;         // [B][nblk][G][3] = (count, mean, M2)
     const float* coef;  // [B][C][2] = (a, b) per (image, channel), written by gn_finalize_chunks_kernel, or NULL: the apply threads compute them
-    // ride-along chunk statistics folded by the apply threads themselves (small maps: few partials - no finalize launch): per source
-    // [B][P][C_src / gran][2] = (sum, sum of squares); cs0 == NULL: not in use
-    const float* cs0; const float* cs1; int cP0, cP1, cg0, cg1;
 };
 
 template <typename T>
@@ -399,34 +396,6 @@ __device__ __forceinline__ void gn_channel_coefs(const GNParams& p, const float*
         const int c = c0 + j;
         const int g = c / p.gs;
         if (stat) { mean = stat[((int64_t)b * p.G + g) * 2]; rstd = stat[((int64_t)b * p.G + g) * 2 + 1]; }
-        else if (p.cs0) {
-            if (g != gprev) {
-                // few (chunk, partial) items per group: every thread folds its group itself, f64, fixed order (chunks ascending,
-                // partials ascending) - the walk of gn_finalize_chunks_kernel without the launch
-                double sa = 0.0, sq = 0.0;
-                const int nq0 = p.C0 / p.cg0, nq1 = p.C1 > 0 ? p.C1 / p.cg1 : 0;
-                int ch = g * p.gs;
-                const int ch1 = ch + p.gs;
-                while (ch < ch1) {
-                    const bool second = ch >= p.C0;
-                    const float* src = second ? p.cs1 : p.cs0;
-                    const int gr = second ? p.cg1 : p.cg0, P = second ? p.cP1 : p.cP0, nq = second ? nq1 : nq0;
-                    const float* base = src + ((int64_t)b * P * nq + (second ? ch - p.C0 : ch) / gr) * 2;
-                    for (int pp = 0; pp < P; ++pp) {
-                        const float2 v = *reinterpret_cast<const float2*>(base + (int64_t)pp * nq * 2);
-                        sa += (double)v.x; sq += (double)v.y;
-                    }
-                    ch += gr;
-                }
-                const double N = (double)p.HW * p.gs;
-                const double mu = sa / N;
-                double var = sq / N - mu * mu;
-                if (var < 0.0) var = 0.0;
-                mean = (float)mu;
-                rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-                gprev = g;
-            }
-        }
         else if (g != gprev) {
             // few partials (small maps): every thread folds them itself, same f64 Chan merge and order as gn_finalize
             const double* w = p.ws + ((int64_t)b * p.nblk * p.G + g) * 3;
@@ -568,7 +537,6 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
     p.C0 = C0; p.C1 = C1; p.C = C0 + C1; p.B = B; p.HW = HW; p.G = groups; p.gs = p.C / groups;
     p.nch = p.C / per;
     p.coef = nullptr;
-    p.cs0 = nullptr; p.cs1 = nullptr; p.cP0 = p.cP1 = 0; p.cg0 = p.cg1 = 8;
     p.tpp = p.nch < NT ? p.nch : NT;
     p.nslot = cdiv(p.nch, p.tpp);
     p.ps = NT / p.tpp; if (p.ps < 1) p.ps = 1;
@@ -602,9 +570,6 @@ static int finalize_tpg(int gs, int P0, int P1, int C0, int C1) {
     return tpg;
 }
 #define FIN_GRID(G, B, tpg) dim3(cdiv((G), NT / (tpg)), (B))
-#ifndef GN_INLINE_ITEMS
-#define GN_INLINE_ITEMS 64                          /* (chunk, partial) items per group up to which the apply threads fold them inline */
-#endif
 
 // Pixels per apply workgroup: `unit` (= ps x unroll x 4 trips) for the big maps, capped so the grid stays <= GN_APPLY_MAXBLK
 // workgroups; halved down to `ps` (one chunk per thread) while the launch would have fewer than 512 workgroups - the 8x8 ... 32x32
@@ -700,20 +665,12 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     // the finalize kernel also folds gamma / beta / FiLM into one (a, b) pair per (image, channel): the apply threads then start
     // with four 16-byte loads instead of five scalar loads and the algebra per channel
     float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
-    // few (chunk, partial) items per group (the 8x8 ... 32x32 levels): the apply threads fold them themselves and the finalize launch
-    // (5-7 us for microseconds of work; ~100 of them per NLC step) disappears
-    const int64_t items = (int64_t)(p.gs / (g0 < g1 ? g0 : g1)) * (P0 > P1 ? P0 : P1);
-    if (items <= GN_INLINE_ITEMS) {
-        p.cs0 = stats0; p.cs1 = stats1; p.cP0 = P0; p.cP1 = P1; p.cg0 = g0; p.cg1 = g1;
-        stat = nullptr;
-    } else {
     const int tpg = finalize_tpg(p.gs, P0, P1, C0, C1);
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
                        eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, g1);
 #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
     p.coef = coef;
 #endif
-    }
     NLC_SWITCH_16(dtype, hipLaunchKernelGGL(gn_apply_fast_kernel<T16>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb));
     NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
     return NLC_OK;
@@ -744,17 +701,12 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
     float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
     if (stats0) {
         float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
-        if ((int64_t)(p.gs / g0) * P0 <= GN_INLINE_ITEMS) {
-            p.cs0 = stats0; p.cP0 = P0; p.cg0 = g0;
-            stat = nullptr;
-        } else {
         const int tpg = finalize_tpg(p.gs, P0, 0, C, 0);
         hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
                            groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, 8);
-#ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
-        p.coef = coef;
+    #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
+    p.coef = coef;
 #endif
-        }
     } else {
         const size_t lds_stats = (size_t)p.ps * p.C * 3 * sizeof(float);
         NLC_REQUIRE(lds_stats <= 64 * 1024, "nlc_groupnorm_pool2x2: LDS budget exceeded (C=%d)", C);
