@@ -171,7 +171,23 @@ class AdmWorkload:
         """BASELINE.json's metric is "images/sec ...; per-pixel L-inf vs CPU ref": the HIP path in the BENCHMARKED precision on the
         oracle leg's own seeded x_T (B = 1), compared timestep by timestep with what the oracle computed there.  `linf` / `rms`:
         the sample the loop would return after the last compared timestep (the clipped x0 estimate, in [-1, 1]); `sigma_rel`:
-        the NLC-corrected sigma of that timestep."""
+        the NLC-corrected sigma of that timestep.  A 16-bit run also reports the same comparison for `f32x3` - the precision of these
+        kernels that carries the 1e-3 gate - under "f32x3" (same image, same timesteps)."""
+        out = self._parity_one(dtype_name)
+        if out is not None and dtype_name in ("bf16", "f16"):
+            for m in (self.exp.model, self.exp.sigma_model):
+                set_precision(m, PRECISIONS["f32x3"])
+            try:
+                ref = self._parity_one("f32x3")
+            finally:
+                for m in (self.exp.model, self.exp.sigma_model):
+                    set_precision(m, PRECISIONS[dtype_name])
+            if ref is not None:
+                ref.pop("what", None)
+                out["f32x3"] = ref
+        return out
+
+    def _parity_one(self, dtype_name):
         tr = getattr(self, "oracle_trace", None)
         if not tr or not tr["x0"]:
             return None
