@@ -526,9 +526,10 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     const int target = (p.tuning & 16384) ? 256 : 512;           // workgroups aimed at (A/B: bit 14 = one per CU)
     if (tiles >= target) return 1;
     int s = cdiv(target, tiles);
-    const int min_cb = k3 ? 2 : 8;                   // >= 18 (3x3) / 8 (1x1) k-steps per split
+    const bool fine = (p.tuning & 0x20000) != 0;     // A/B bit 17: one channel block (9 / 4 k-steps) per split, up to 16 splits
+    const int min_cb = fine ? (k3 ? 1 : 4) : (k3 ? 2 : 8);       // >= 18 (3x3) / 8 (1x1) k-steps per split
     if (s > ncb / min_cb) s = ncb / min_cb;
-    if (s > 8) s = 8;
+    if (s > (fine ? 16 : 8)) s = fine ? 16 : 8;
     return s < 2 ? 1 : s;
 }
 
