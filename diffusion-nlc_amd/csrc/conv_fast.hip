@@ -389,10 +389,8 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                 *reinterpret_cast<uint4*>(op) = pk0;
                 *reinterpret_cast<uint4*>(op + 8) = pk1;
                 if (has_stats) {         // of the STORED (rounded) values - what the GroupNorm that follows reads
-                    float s0[8], s1[8];
-                    chunk_to_f32<T>(pk0, s0); chunk_to_f32<T>(pk1, s1);
                     if (pix_stats) st16.zero();
-                    st16.add8(0, s0); st16.add8(1, s1);
+                    st16.add_chunk<T>(0, pk0); st16.add_chunk<T>(1, pk1);
                     if (pix_stats) {     // [b][pixel][chunk][{sum, sumsq}], stats_P = Hout * Wout
                         const int b = m / HWo;
                         st16.store(p.stats, (int64_t)b * p.stats_P + (m - b * HWo), p.Cout, n, p.stats_gran);
@@ -447,10 +445,8 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                     *reinterpret_cast<uint4*>(op + c * PER) = pk;
                     if constexpr (sizeof(T) == 2) {
                         if (p.stats) {
-                            float sv[8];
-                            chunk_to_f32<T>(pk, sv);
                             if (pix_stats && c == 0) st16.zero();
-                            st16.add8(c, sv);
+                            st16.add_chunk<T>(c, pk);
                         }
                     }
                 }

@@ -85,7 +85,10 @@ struct TileH { int tb, y0, x0, n0, cb0, cb1, ks, tix; };     // cb0 / cb1 / ks /
 // `lo` halves of the same eight channels (conv_params.h: f16x3_split4; the weights arrive packed that way).  The two fragment reads
 // of a k-step that used to fetch the two k-halves now fetch a lane's eight hi and its eight lo values, and a k-step is
 // hi*hi, hi*lo, lo*hi = 48 v_mfma_f32_16x16x32_f16 per wave instead of 64 exact-f32 MFMAs at 1/8 the rate each.
-template <typename T, bool GN, bool SPLIT = false, bool X3 = false>
+// CF (16-bit, no SPLIT / GN / X3; chosen by the dispatch): whole 128-channel N-tiles and a 16-byte-aligned bias (and embedding, if any) -
+// the next tile's initial accumulator values are fetched by explicit vector loads at the top of the epilogue and waited for with a
+// count of this path's own stores (see the epilogue).  A separate instantiation so that no other variant's loads share its registers.
+template <typename T, bool GN, bool SPLIT = false, bool X3 = false, bool CF = false>
 __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = ElemTraits<T>::kPerChunk;
@@ -354,11 +357,13 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     };
     // sum over the 16 lanes of a DPP row (= the 16 pixels fr of one quarter-wave), result in every lane; VALU only
     // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) - a __shfl_xor is a ds_bpermute, ~100 cycles each
+    // (one v_add_f32 with a DPP source operand per stage: through __builtin_amdgcn_update_dpp the compiler emitted a zeroing move,
+    //  a DPP move and a packed add per stage and value - 80 instructions for the eight statistics of a tile instead of 32)
     auto row16_sum = [&](float x) {
-        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
-        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
-        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
-        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+        asm("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
         return x;
     };
     auto init_acc = [&](const float (&cadd)[16]) {
@@ -367,9 +372,88 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cadd[j * 4], cadd[j * 4 + 1], cadd[j * 4 + 2], cadd[j * 4 + 3]};
     };
-    auto epilogue = [&](const TileH& t, const TileH& nx) {
+    // reduce a lane's statistics over the 16 pixel lanes (fr) of its quarter-wave in a fixed order, then one 16-byte store per
+    // (patch, M-wave, 16-channel slice): stats[b][partial][chunk][{sum, sumsq}]
+    auto emit_stats = [&](Stat16& st16, const TileH& t, int n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
+        if (fr == 0) {
+            const int part = ((t.y0 / PATCH) * tiles_x + t.x0 / PATCH) * 4 + wm;
+            st16.store(p.stats, (int64_t)t.tb * p.stats_P + part, p.Cout, n, p.stats_gran);
+        }
+    };
+    // Pins the accumulator initialisation where it is written.  Left free, the compiler sank it (and the wait for the bias loads
+    // that feed it) past the loop back-edge, where its wait-count pass assumes the worst predecessor: `s_waitcnt vmcnt(0)` at the top
+    // of every tile (tools/halo_stamps.py: ~5.8 k cycles on the first k-step of a tile against 1.25 k in mid-tile).
+    auto pin_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+    };
+    // CF: counted wait for the explicit bias / embedding loads of the epilogue (N = vector-memory operations this path issued after
+    // them), then cnext = bias + embedding
+    auto cadd_wait = [&](auto n_c, f32x4_t (&cq)[4], f32x4_t (&eq)[4], float (&cnext)[16]) {
+        constexpr int N = decltype(n_c)::value;
+        if (p.emb) {
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(eq[0]), "+v"(eq[1]), "+v"(eq[2]), "+v"(eq[3])
+                         : "n"(N) : "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cnext[q * 4 + r] = cq[q][r] + eq[q][r];
+        } else {
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]) : "n"(N) : "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cnext[q * 4 + r] = cq[q][r];
+        }
+    };
+    // The output stores of an epilogue retire in issue order with everything else (one vmcnt): a counted wait for a weight tile that
+    // was issued AFTER them waits for their acknowledgement first - measured (tools/halo_stamps.py) at ~5.8 k cycles on the first
+    // k-step of every tile against 1.25 k for a step in mid-tile.  So the weight tile the next tile's step 0 would issue (its k-step 3)
+    // goes out at the START of the epilogue, ahead of the stores (its stage was freed by the last step's barrier), step 0 issues none,
+    // and the counted waits of steps 0 and 1 leave the eight row stores in flight: the first wait that covers them is step 2's, three
+    // k-steps after they were issued.  post_ep: 2 / 1 = step 0 / 1 of a tile that follows such an epilogue (wave-uniform).
+    constexpr bool EARLY_W = FOLD && !SPLIT && !has_xf;
+    int post_ep = 0;
+    int bcur = 0, hs = 0;                            // weight stage / halo stage of the current k-step (run across tiles)
+    auto epilogue = [&](const TileH& t, const TileH& nx, bool has_next) {
+        bool early = false;
+        if constexpr (EARLY_W) {
+            early = has_next && vec_ok && (t.n0 + BN <= p.Cout) && p.out_mode == NLC_OUT_NHWC && p.act == NLC_ACT_NONE;     // workgroup-uniform: the hot path below
+            if (early) issue_B(nx.n0, 0, 3, (bcur + 3) & 3);
+        }
         float cnext[16];
-        if constexpr (SPLIT) {
+        // The next tile's bias vector, requested NOW so that it lands while this tile is stored.  As plain C++ loads the compiler sank
+        // them (and their wait) to the accumulator initialisation behind the stores - `s_waitcnt vmcnt(3..0)`: the load latency in the
+        // open and, the counter being in order, a drain of every store and DMA ahead of them.  So (16-bit, aligned bias, no embedding,
+        // whole 16-channel slices): four explicit global_load_dwordx4, and the wait below counts only what this path issued after them.
+        f32x4_t cq[4], eq[4];
+        constexpr bool cfast = CF;
+        static_assert(!CF || (FOLD && !SPLIT && !has_xf), "CF: plain 16-bit kernel only");
+        if constexpr (CF) {
+            // SGPR base + per-lane byte offset (lane >> 4) * 64, recomputed here on purpose: as a loop-invariant 64-bit per-lane
+            // address it was spilled, and the reload's wait drained the DMA in flight
+            unsigned voff;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\t"
+                         "v_lshrrev_b32 %0, 4, %0\n\tv_lshlrev_b32 %0, 6, %0" : "=v"(voff));
+            const float* sb = p.bias + nx.n0 + wn * 64;          // wave-uniform
+            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                         "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                         "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
+                         "global_load_dwordx4 %3, %4, %5 offset:48"
+                         : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]) : "v"(voff), "s"(sb) : "memory");
+            if (p.emb) {
+                const float* se = p.emb + (int64_t)nx.tb * p.emb_stride + nx.n0 + wn * 64;
+                asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                             "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                             "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
+                             "global_load_dwordx4 %3, %4, %5 offset:48"
+                             : "=&v"(eq[0]), "=&v"(eq[1]), "=&v"(eq[2]), "=&v"(eq[3]) : "v"(voff), "s"(se) : "memory");
+            }
+        } else if constexpr (SPLIT) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) cnext[k] = 0.f;           // raw partial sums: bias / embedding are added by the last arriver
         } else {
@@ -379,6 +463,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         Stat16 st16;                                 // this lane's 16 channels over its 4 pixels (ride-along GroupNorm statistics)
         st16.zero();
         bool done = false;
+        bool inited = false;                         // the vectorised path below ran and initialised the next tile's accumulators itself
         bool parked = false;                         // SPLIT: this workgroup was not the last to arrive at its tile - no output from it
         if constexpr (SPLIT) {                       // dispatch: bf16, Cout % 128 == 0
             // The partial sums cross workgroups that may sit on different XCDs.  Memory-ordering argument (gfx950; MI355X_MICROARCH.md,
@@ -465,21 +550,44 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             if (!done)
             // hot path (bf16, whole 16-channel slice, NHWC): the option switches are hoisted out of the element loops;
             // measured with stamps, the general path below spent ~9 k cycles per tile on ~19 VALU per output element
-            if (vec_ok && n + 16 <= p.Cout && p.out_mode == NLC_OUT_NHWC) {
+            // (no fused activation here: in the networks only the 1x1 "linear" layers carry one, and with both activations' code in this
+            //  path the compiler merged three variants' registers with a shuffle per stored dword; the general path below has them)
+            if (vec_ok && t.n0 + BN <= p.Cout && p.out_mode == NLC_OUT_NHWC && p.act == NLC_ACT_NONE) {      // workgroup-uniform
                 const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
                 const float sc = p.out_scale;
-                const int act = p.act;
+                // all eight residual chunks are requested before the first row is stored (the output may alias nothing the compiler can
+                // see, so it kept each row's loads behind the previous row's stores: four exposed memory latencies per tile)
+                // row i of the lane's four is one image row further down: one address per tile, then a constant stride
+                const int64_t m0 = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4) * p.Wout + t.x0 + fr;
+                const int64_t rstride = (int64_t)p.Wout * p.Cout;
+                T* const op0 = reinterpret_cast<T*>(p.out) + m0 * p.Cout + n;
+                uint4 rq0[4], rq1[4];
+                if (has_res) {
+                    if (!p.res_ups) {
+                        const T* rp0 = reinterpret_cast<const T*>(p.res) + m0 * p.Cout + n;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            rq0[i] = *reinterpret_cast<const uint4*>(rp0 + i * rstride);
+                            rq1[i] = *reinterpret_cast<const uint4*>(rp0 + i * rstride + 8);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const T* rp = reinterpret_cast<const T*>(p.res) + res_row(p, t.tb, t.y0 + wm * 4 + i, t.x0 + fr) * p.Cout + n;
+                            rq0[i] = *reinterpret_cast<const uint4*>(rp);
+                            rq1[i] = *reinterpret_cast<const uint4*>(rp + 8);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int64_t m = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4 + i) * p.Wout + t.x0 + fr;
                     float v[16];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg];
                     if (has_res) {
-                        const T* rp = reinterpret_cast<const T*>(p.res) + res_row(p, t.tb, t.y0 + wm * 4 + i, t.x0 + fr) * p.Cout + n;
-                        const uint4 r0 = *reinterpret_cast<const uint4*>(rp), r1 = *reinterpret_cast<const uint4*>(rp + 8);
+                        const uint4 r0 = rq0[i], r1 = rq1[i];
                         float rr[16];
                         chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
 #pragma unroll
@@ -489,24 +597,25 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) v[k] *= sc;
                     }
-                    if (act == NLC_ACT_SILU) {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) v[k] = silu_f(v[k]);
-                    } else if (act == NLC_ACT_GELU) {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) v[k] = gelu_erf(v[k]);
-                    }
-                    T* op = reinterpret_cast<T*>(p.out) + m * p.Cout + n;
+                    T* op = op0 + i * rstride;
                     const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
                     *reinterpret_cast<uint4*>(op) = pk0;
                     *reinterpret_cast<uint4*>(op + 8) = pk1;
                     if (has_stats) {     // of the STORED (rounded) values - what the GroupNorm that follows reads
-                        float s0[8], s1[8];
-                        chunk_to_f32<T>(pk0, s0); chunk_to_f32<T>(pk1, s1);
-                        st16.add8(0, s0); st16.add8(1, s1);
+                        st16.add_chunk<T>(0, pk0); st16.add_chunk<T>(1, pk1);
                     }
                 }
+                if (has_stats) emit_stats(st16, t, n);
+                // the next tile's accumulators, initialised INSIDE this straight-line block: at the common tail below the wait-count
+                // pass has to merge every epilogue variant and drains the counter (vmcnt(0): all eight store acknowledgements + the DMA)
+                if constexpr (cfast) {
+                    // in order behind the bias (and embedding) loads: exactly this block's eight row stores (+ its statistics stores)
+                    cadd_wait(std::integral_constant<int, 8>{}, cq, eq, cnext);
+                }
+                init_acc(cnext);
+                pin_acc();
                 done = true;
+                inited = true;
             }
         }
         if (!done && n < p.Cout) {
@@ -555,11 +664,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                             const uint4 pk = f32_to_chunk<T>(v + c * PER);
                             *reinterpret_cast<uint4*>(op + c * PER) = pk;
                             if constexpr (sizeof(T) == 2) {
-                                if (p.stats) {           // GroupNorm statistics of what was just stored (the rounded values)
-                                    float sv[8];
-                                    chunk_to_f32<T>(pk, sv);
-                                    st16.add8(c, sv);
-                                }
+                                if (p.stats) st16.add_chunk<T>(c, pk);       // GroupNorm statistics of what was just stored (the rounded values)
                             }
                         }
                     } else {
@@ -574,19 +679,17 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 }
             }
         }
-        if constexpr (sizeof(T) == 2) {
-            if (p.stats && n + 16 <= p.Cout && !parked) {
-                // reduce over the 16 pixel lanes (fr) of this quarter-wave in a fixed order, then one 16-byte store per
-                // (patch, M-wave, 16-channel slice): stats[b][partial][chunk][{sum, sumsq}]
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
-                if (fr == 0) {
-                    const int part = ((t.y0 / PATCH) * tiles_x + t.x0 / PATCH) * 4 + wm;
-                    st16.store(p.stats, (int64_t)t.tb * p.stats_P + part, p.Cout, n, p.stats_gran);
-                }
+        if (!inited) {
+            if constexpr (sizeof(T) == 2) {
+                if (p.stats && n + 16 <= p.Cout && !parked) emit_stats(st16, t, n);
             }
+            if constexpr (cfast) {     // (a path other than the vectorised one ran: unknown number of stores since the loads - drain)
+                cadd_wait(std::integral_constant<int, 0>{}, cq, eq, cnext);
+            }
+            init_acc(cnext);
+            pin_acc();
         }
-        init_acc(cnext);
+        post_ep = early ? 2 : 0;
     };
 
     // ---- prologue (first tile only): halo of block 0, weights of steps 0..2
@@ -624,10 +727,12 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // (Tried and measured slower on this kernel, 1.18 vs 1.12 ms on 256->256 @256^2: running SIMD partner waves in
     //  complementary orders by giving waves 0-3 / 4-7 their barrier at different points of one instruction stream.)
     constexpr int wdist = 3;                         // weight tiles run 3 k-steps ahead
-    int bcur = 0, hs = 0;                            // weight stage / halo stage of the current k-step (run across tiles)
+    // The list entry after next is decoded (five integer divisions, ~1 k cycles of dependent scalar work) inside the current tile's
+    // k-loop, where the matrix pipe covers it; at the top of a tile it sat between the epilogue and the first MFMA.
+    TileH nxt = tl + gx < chunk_len ? decode(tl + gx) : cur;
+    TileH nxt2 = nxt;
     for (;;) {
         const bool has_next = tl + gx < chunk_len;
-        const TileH nxt = has_next ? decode(tl + gx) : cur;
         int kt = 0;
         const int c_end = t_cb1(cur), nkt = t_nk(cur);
         for (int cb = t_cb0(cur); cb < c_end; ++cb) {
@@ -644,15 +749,33 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // weight DMA re-fetches the last tile into a free stage and the fragment prefetch reads
                 // stale-but-valid LDS; neither result is used (straight-line body, no data-dependent branches).
                 auto issue_dma = [&]() {
+                    if constexpr (tap == 4) {
+                        if (kt == 4) nxt2 = tl + 2 * gx < chunk_len ? decode(tl + 2 * gx) : nxt;       // workgroup-uniform
+                    }
                     const int k3 = kt + wdist;
                     const bool wrap = k3 >= nkt;
-                    issue_B(wrap ? nxt.n0 : cur.n0, wrap && has_next ? t_cb0(nxt) : t_cb0(cur), wrap ? (has_next ? k3 - nkt : nkt - 1) : k3, (bcur + wdist) & 3);
+                    if (!(EARLY_W && tap == 0 && post_ep == 2))      // (already issued by the epilogue)
+                        issue_B(wrap ? nxt.n0 : cur.n0, wrap && has_next ? t_cb0(nxt) : t_cb0(cur), wrap ? (has_next ? k3 - nkt : nkt - 1) : k3, (bcur + wdist) & 3);
                     // the next halo goes out two instructions per step over taps 0-2, AFTER the step's weights (needed first)
                     if constexpr (tap <= 2) {
                         if (more) {
                             if constexpr (tap == 0) {
-                                if (last_cb) halo_addr(nxt, t_seg(nxt));
-                                else if (p.C1 > 0 && cb + 1 == cbs1) halo_addr(cur, 1);
+                                // The tile coordinates go through an empty asm INSIDE the branch: the address arithmetic (~250 VALU with
+                                // 64-bit multiplies) is invariant in the channel-block loop, and the compiler hoisted it - both variants,
+                                // speculatively - to the top of every tile, between the epilogue and the first MFMA (tools/halo_stamps.py:
+                                // ~2.6 k cycles there); here it runs between two MFMA clusters of a step.  A next list entry on the same
+                                // patch (the other N-tile: N-tile fastest) keeps the addresses it has.
+                                if (last_cb) {
+                                    if (p.C1 > 0 || nxt.tb != cur.tb || nxt.y0 != cur.y0 || nxt.x0 != cur.x0) {
+                                        TileH tn = nxt;
+                                        asm volatile("" : "+s"(tn.tb), "+s"(tn.y0), "+s"(tn.x0));
+                                        halo_addr(tn, t_seg(nxt));
+                                    }
+                                } else if (p.C1 > 0 && cb + 1 == cbs1) {
+                                    TileH tn = cur;
+                                    asm volatile("" : "+s"(tn.tb), "+s"(tn.y0), "+s"(tn.x0));
+                                    halo_addr(tn, 1);
+                                }
                                 if (coef_wave) issue_coef(last_cb ? 0 : cb + 1, hs ^ 1);     // BEFORE the halo rows: retired first
                             }
                             issue_A(last_cb ? t_cb0(nxt) : cb + 1, hs ^ 1, std::integral_constant<int, 2 * tap>{}, std::integral_constant<int, 2>{});
@@ -739,10 +862,23 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // this step's weights kt+3 (NB) and the halo instructions issued at this step or the previous one
                 // (issue order per step: weights, then 2 halo instructions at taps 0-2)
                 if constexpr (tap == 0) {
-                    if (more) { if (coef_wave) dma_wait_h<NB + 3>(); else dma_wait_h<NB + 2>(); } else dma_wait_h<NB>();
+                    if (EARLY_W && post_ep == 2) {
+                        // younger than the weights of step 2 (which this wait is for): the early weight tile, 8 row stores, this step's halo
+                        if (more) dma_wait_h<NB + 8 + 2>(); else dma_wait_h<NB + 8>();
+                        post_ep = 1;
+                    }
+                    else if (more) { if (coef_wave) dma_wait_h<NB + 3>(); else dma_wait_h<NB + 2>(); } else dma_wait_h<NB>();
+                }
+                else if constexpr (tap == 1) {
+                    if (EARLY_W && post_ep == 1) {
+                        // younger than the early weight tile: 8 row stores, halo of steps 0 and 1, this step's weights
+                        if (more) dma_wait_h<8 + NB + 4>(); else dma_wait_h<8 + NB>();
+                        post_ep = 0;
+                    }
+                    else if (more) dma_wait_h<NB + 4>(); else dma_wait_h<NB>();
                 }
                 else if constexpr (tap == 3) { if (more) dma_wait_h<NB + 2>(); else dma_wait_h<NB>(); }
-                else if constexpr (tap == 1 || tap == 2) { if (more) dma_wait_h<NB + 4>(); else dma_wait_h<NB>(); }
+                else if constexpr (tap == 2) { if (more) dma_wait_h<NB + 4>(); else dma_wait_h<NB>(); }
                 else dma_wait_h<NB>();
                 __syncthreads();
                 bcur = bnext;
@@ -753,24 +889,25 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
             hs ^= 1;
         }
-        epilogue(cur, nxt);                          // registers -> global, asynchronous stores; no LDS, no barrier
+        epilogue(cur, nxt, has_next);                // registers -> global, asynchronous stores; no LDS, no barrier
         if (!has_next) break;
         cur = nxt;
+        nxt = nxt2;
         tl += gx;
     }
     dma_wait_h<0>();          // the redundant tail fetches
 }
 
-template <typename T, bool GN, bool SPLIT = false, bool X3 = false>
+template <typename T, bool GN, bool SPLIT = false, bool X3 = false, bool CF = false>
 int launch_halo(const KParams& p, hipStream_t stream) {
     static DeviceOnce once;
     const int slot = nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, GN, SPLIT, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<T, GN, SPLIT, X3, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_LDS);
     });
     const int ncu = once.ncu[slot];
     const int nblk = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT * (SPLIT ? p.ksplit : 1);
     const int grid = nblk < ncu ? nblk : ncu;        // one persistent workgroup per CU (154 KiB of LDS each)
-    hipLaunchKernelGGL((conv_halo_kernel<T, GN, SPLIT, X3>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
+    hipLaunchKernelGGL((conv_halo_kernel<T, GN, SPLIT, X3, CF>), dim3(grid), dim3(HT), HALO_LDS, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(halo): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
@@ -844,8 +981,11 @@ int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
         return launch_halo<bf16_raw, false, true>(p, stream);
     }
     if (!halo_plain_ok(p, dtype)) return NLC_EUNSUPPORTED;
-    if (dtype == NLC_BF16) return p.gn_coef ? launch_halo<bf16_raw, true>(p, stream) : launch_halo<bf16_raw, false>(p, stream);
-    if (dtype == NLC_F16) return launch_halo<f16_raw, false>(p, stream);      // (GroupNorm prologue: bf16 instantiation only - it is off by default)
+    // CF instantiation: whole N-tiles, bias (and embedding) readable as aligned float4
+    const bool cf = nlc_is16(dtype) && !p.gn_coef && (p.Cout % BN) == 0 && p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 &&
+                    (!p.emb || ((reinterpret_cast<uintptr_t>(p.emb) & 15) == 0 && (p.emb_stride & 3) == 0));
+    if (dtype == NLC_BF16) return p.gn_coef ? launch_halo<bf16_raw, true>(p, stream) : cf ? launch_halo<bf16_raw, false, false, false, true>(p, stream) : launch_halo<bf16_raw, false>(p, stream);
+    if (dtype == NLC_F16) return cf ? launch_halo<f16_raw, false, false, false, true>(p, stream) : launch_halo<f16_raw, false>(p, stream);      // (GroupNorm prologue: bf16 instantiation only - it is off by default)
     if (p.math == NLC_MATH_F16X3) return launch_halo<float, false, false, true>(p, stream);
     return launch_halo<float, false>(p, stream);
 }

@@ -45,6 +45,27 @@ struct Stat16 {
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s[2 * half + (k >> 2)] += sv[k]; q[2 * half + (k >> 2)] = fmaf(sv[k], sv[k], q[2 * half + (k >> 2)]); }
     }
+    // the same from the packed 16-byte chunk as stored (16-bit types): v_dot2c_f32_{bf16,f16} adds both halves of a dword in one
+    // instruction - sum = dot2(d, (1, 1)), sum of squares = dot2(d, d) - 16 VALU per 16 channels instead of 48 (unpack, add, fma)
+    template <typename T> __device__ __forceinline__ void add_chunk(int half, const uint4& pk) {
+        static_assert(sizeof(T) == 2, "16-bit storage only");
+        const unsigned d[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = 2 * half + (k >> 1);
+            if constexpr (std::is_same<T, bf16_raw>::value) {
+                typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+                const v2 x = __builtin_bit_cast(v2, d[k]);
+                s[g] = __builtin_amdgcn_fdot2_f32_bf16(x, __builtin_bit_cast(v2, 0x3f803f80u), s[g], false);
+                q[g] = __builtin_amdgcn_fdot2_f32_bf16(x, x, q[g], false);
+            } else {
+                typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+                const v2 x = __builtin_bit_cast(v2, d[k]);
+                s[g] = __builtin_amdgcn_fdot2(x, __builtin_bit_cast(v2, 0x3c003c00u), s[g], false);
+                q[g] = __builtin_amdgcn_fdot2(x, x, q[g], false);
+            }
+        }
+    }
     // values already reduced over whatever shares the partial; n = the lane's first channel
     __device__ __forceinline__ void store(float* stats, int64_t row /* b * P + partial */, int Cout, int n, int gran) const {
         if (gran == 4) {

@@ -245,11 +245,7 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
                     for (int c = 0; c < 2; ++c) {
                         const uint4 pk = f32_to_chunk<T>(v + c * 8);
                         *reinterpret_cast<uint4*>(op + c * 8) = pk;
-                        if (stats) {
-                            float sv[8];
-                            chunk_to_f32<T>(pk, sv);
-                            st16.add8(c, sv);
-                        }
+                        if (stats) st16.add_chunk<T>(c, pk);
                     }
                 } else {
 #pragma unroll

@@ -67,10 +67,13 @@ def main():
     ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a ResBlock)")
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights: same instruction stream, least energy per MFMA "
                     "(what the clock does to the rate: MI355X_MICROARCH.md 'DVFS give-back')")
+    ap.add_argument("--shape", action="append", default=[], help="extra shape H,Cin,Cout,k (replaces the list; may repeat)")
     args = ap.parse_args()
     global SHAPES
     if args.set == "small":
         SHAPES = SMALL
+    if args.shape:
+        SHAPES = [tuple(int(v) for v in sh.split(",")) + (f"custom {sh}",) for sh in args.shape]
     if args.only >= 0:
         SHAPES = SHAPES[args.only:args.only + 1]
     elif args.first:
