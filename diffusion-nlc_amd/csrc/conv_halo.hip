@@ -165,6 +165,11 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         const int C = seg ? p.C1 : p.C0;
         hvalid = 0;
         if (coef_wave) cbase = reinterpret_cast<const char*>(p.gn_coef) + ((int64_t)t.tb * p.Ctot * 2) * 4;
+        // pixel indices fit 32 bits (dispatch: B * Hout * Wout < 2^31); one 32 x 32 -> 64-bit multiply-add per row for the byte offset
+        const unsigned pixbytes = (unsigned)C * ES;                   // wave-uniform
+        const int row0 = t.tb * p.Hin;                                // wave-uniform: the image's first source row
+        const unsigned choff = (unsigned)(hchunk * PER * ES);
+        const int sh = p.ups ? 1 : 0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int R = (wave + 8 * j) * 8 + lrow;
@@ -174,9 +179,8 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             // upsample fused the halo row is fetched from source pixel (iy >> 1, ix >> 1) - the LDS image holds the
             // upsampled patch, so the k-loop does not know about it (src/unet_adm.py:107-109)
             const bool ok = R < HALO_ROWS && iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout;
-            const int sy = p.ups ? iy >> 1 : iy, sx = p.ups ? ix >> 1 : ix;
-            const int64_t pixel = ((int64_t)t.tb * p.Hin + sy) * p.Win + sx;
-            haddr[j] = ok ? src + (pixel * C + hchunk * PER) * ES : zero;
+            const unsigned pixel = (unsigned)((row0 + (iy >> sh)) * p.Win + (ix >> sh));       // (garbage when !ok: not used)
+            haddr[j] = ok ? src + ((uint64_t)pixel * pixbytes + choff) : zero;
             hvalid |= (ok ? 1u : 0u) << j;
         }
     };
