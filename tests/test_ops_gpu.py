@@ -817,6 +817,42 @@ def test_split_k_launches_leave_the_arrival_counters_zero():
         ops.CONV_POLICY = old
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("with_emb", [False, True], ids=["bias", "bias+emb"])
+@pytest.mark.parametrize("with_res", [False, True], ids=["nores", "res"])
+def test_halo_conv_aligned_bias_instantiation_matches_the_general_one(dtype, with_emb, with_res):
+    """conv_halo_kernel's CF instantiation (whole N-tiles, 16-byte-aligned bias / embedding: explicit loads of the next tile's
+    initial accumulator values, counted waits, the next tile's weights issued ahead of the stores) must be bit-identical to the
+    general instantiation, which the same call takes when the bias pointer is not 16-byte aligned.  512 tiles on 256 persistent
+    workgroups: every workgroup crosses a tile boundary, half of them onto a new patch."""
+    import dataclasses
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(_seed(("cf", str(dtype), with_emb, with_res)))
+    B, Cin, H, Cout = 4, 64, 128, 256
+    x = _nhwc(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pw = ops.pack_conv(w, b, dtype, _dev())
+    assert pw.bias.data_ptr() % 16 == 0
+    shifted = torch.zeros(Cout + 4, device=_dev(), dtype=torch.float32)
+    shifted[1:Cout + 1] = pw.bias
+    pw_unaligned = dataclasses.replace(pw, bias=shifted[1:Cout + 1])
+    assert pw_unaligned.bias.data_ptr() % 16 == 4
+    emb = torch.randn(B, Cout, generator=g).to(_dev()) if with_emb else None
+    res = _nhwc(torch.randn(B, Cout, H, H, generator=g), dtype) if with_res else None
+    ya, yb = (ops.conv2d(x, q, emb=emb, res=res) for q in (pw, pw_unaligned))
+    sa, sb = getattr(ya, "_nlc_stats", None), getattr(yb, "_nlc_stats", None)
+    assert sa is not None and sb is not None, "both launches emit ride-along statistics"
+    assert torch.equal(ya, yb)
+    assert torch.equal(sa, sb)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), _rt(w, dtype).to(_dev()), b.to(_dev()), padding=1)
+    if with_emb:
+        ref = ref + emb[:, :, None, None]
+    if with_res:
+        ref = ref + res.float().permute(0, 3, 1, 2)
+    _close(ya.permute(0, 3, 1, 2), ref.cpu(), _tol(dtype), "CF halo conv")
+
+
 def test_split_k_stress():
     """2 000 back-to-back split-K launches, mixed kernels and levels (halo kernel on the 16x16 level, conv_fast<9> on the 8x8 level,
     conv_fast<1>), through ONE workspace, half of them beside a second stream that keeps the memory system busy: every result is
