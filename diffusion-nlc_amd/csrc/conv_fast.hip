@@ -280,17 +280,23 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     if (p.ksplit > 1) {
         __shared__ int s_last;
         const int ks = p.ksplit;
-        // workspace = [1024 arrival counters][partial sums]: the counters sit in FRONT so that no launch's partials ever cover them
-        auto pbase = [&](int sp) { return p.partial + 1024 + ((((int64_t)sp * nblk + bid) * 4 + wave) * 64) * 64 + lane; };
+        // workspace = [1024 arrival counters][partial sums]: the counters sit in FRONT so that no launch's partials ever cover them.
+        // Partials move as 16-byte transactions, [split][tile][wave][accumulator tile 0..15][lane][4]: one f32x4 accumulator per
+        // instruction, 1 KiB contiguous per wave-instruction - a quarter of the vector-memory instructions of the dword form (a
+        // last arriver read 4 x 128 KiB in 2048 wave-instructions: 9 us of a 35 us launch, tools/fast_stamps.py).  Same cache policy
+        // as before on both sides (sc1: write-through stores, L1-bypassing loads), written as inline asm because the atomic
+        // builtins stop at 8 bytes; the loads are waited for explicitly (the compiler does not see them).
+        auto pbase = [&](int sp) { return p.partial + 1024 + ((((int64_t)sp * nblk + bid) * 4 + wave) * 64) * 64 + lane * 4; };
         {
             float* pp = pbase(blockIdx.y);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        __hip_atomic_store(pp + (i * 16 + j * 4 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (s_nop: a store of more than 8 bytes needs one wait state before a VALU write of its data registers - the
+                    //  hazard recognizer inserts it for the compiler's own stores but cannot see into an asm statement; without it
+                    //  the next tile's v_accvgpr_read overwrote dword 0 of the data for the last lanes still being read)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(pp + (i * 4 + j) * 256), "v"(acc[i][j]) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's partial stores have been acknowledged ...
         __syncthreads();                                             // ... and every lane's, before the arrival is counted
@@ -308,25 +314,55 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         }
         __syncthreads();
         if (!s_last) return;                                         // workgroup-uniform
+        // The number of splits is a compile-time constant inside each case: the loaded registers must reach the wait below untouched
+        // (no select, no copy - the compiler does not know they are still being written), so there is no "if (split exists)" here.
+        auto reduce = [&](auto ks_c) {
+            constexpr int KS = decltype(ks_c)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            for (int s0 = 0; s0 < ks; s0 += 4) {                     // four splits' loads at a time (64 in flight), adds in split order
-                float tmp[4][16];
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float* pp = pbase(s0 + u < ks ? s0 + u : 0) + i * 16 * 64;
+                for (int s0 = 0; s0 < KS; s0 += 4) {                 // up to four splits' loads at a time (16 x 16 bytes in flight), adds in split order
+                    constexpr int NU = KS < 4 ? KS : 4;              // (KS = 5 ... 8: second round of KS - 4)
+                    const int nu = KS - s0 < NU ? KS - s0 : NU;      // compile-time after unrolling
+                    f32x4_t t[4][4];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        tmp[u][k] = s0 + u < ks ? __hip_atomic_load(pp + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    for (int u = 0; u < 4; ++u) {
+                        if (u >= nu) break;
+                        const float* pp = pbase(s0 + u) + i * 4 * 256;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[u][j]) : "v"(pp + j * 256) : "memory");
+                    }
+                    if (nu == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]) :: "memory");
+                    else if (nu == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]),
+                                                   "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]) :: "memory");
+                    else if (nu == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]),
+                                                   "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]),
+                                                   "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[2][2]), "+v"(t[2][3]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]),
+                                      "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[2][2]), "+v"(t[2][3]),
+                                      "+v"(t[3][0]), "+v"(t[3][1]), "+v"(t[3][2]), "+v"(t[3][3]) :: "memory");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u >= nu) break;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] += t[u][j][r];      // split order: 0, 1, 2, ...
+                    }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)                  // + 0.f past ks: exact
-                        acc[i][j][r] = (((acc[i][j][r] + tmp[0][j * 4 + r]) + tmp[1][j * 4 + r]) + tmp[2][j * 4 + r]) + tmp[3][j * 4 + r];
             }
+        };
+        switch (ks) {
+            case 2: reduce(std::integral_constant<int, 2>{}); break;
+            case 3: reduce(std::integral_constant<int, 3>{}); break;
+            case 4: reduce(std::integral_constant<int, 4>{}); break;
+            case 5: reduce(std::integral_constant<int, 5>{}); break;
+            case 6: reduce(std::integral_constant<int, 6>{}); break;
+            case 7: reduce(std::integral_constant<int, 7>{}); break;
+            default: reduce(std::integral_constant<int, 8>{}); break;      // (nlc_conv_fast_ksplit: at most 8)
         }
     }
     if (n >= p.Cout) return;
@@ -522,10 +558,9 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     const int target = (p.tuning & 16384) ? 256 : 512;           // workgroups aimed at (A/B: bit 14 = one per CU)
     if (tiles >= target) return 1;
     int s = cdiv(target, tiles);
-    const bool fine = (p.tuning & 0x20000) != 0;     // A/B bit 17: one channel block (9 / 4 k-steps) per split, up to 16 splits
-    const int min_cb = fine ? (k3 ? 1 : 4) : (k3 ? 2 : 8);       // >= 18 (3x3) / 8 (1x1) k-steps per split
-    if (s > ncb / min_cb) s = ncb / min_cb;
-    if (s > (fine ? 16 : 8)) s = fine ? 16 : 8;
+    const int min_cb = k3 ? 2 : 8;                   // >= 18 (3x3) / 8 (1x1) k-steps per split (one channel block per split, up to 16
+    if (s > ncb / min_cb) s = ncb / min_cb;          //  splits: measured slower, profiles/r03_summary.md section 5)
+    if (s > 8) s = 8;                                // (the read-back in the kernel is instantiated for 2 ... 8)
     return s < 2 ? 1 : s;
 }
 
