@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                     // (s_nop: a store of more than 8 bytes needs one wait state before a VALU write of its data registers - the
                     //  hazard recognizer inserts it for the compiler's own stores but cannot see into an asm statement; without it
                     //  the next tile's v_accvgpr_read overwrote dword 0 of the data for the last lanes still being read)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(pp + (i * 4 + j) * 256), "v"(acc[i][j]) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 0" :: "v"(pp + i * 1024), "v"(acc[i][j]), "n"(j * 1024) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's partial stores have been acknowledged ...
         __syncthreads();                                             // ... and every lane's, before the arrival is counted
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                         const float* pp = pbase(s0 + u) + i * 4 * 256;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[u][j]) : "v"(pp + j * 256) : "memory");
+                            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(t[u][j]) : "v"(pp), "n"(j * 1024) : "memory");
                     }
                     if (nu == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]) :: "memory");
                     else if (nu == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]),

@@ -493,20 +493,21 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             // (tests/test_ops_gpu.py::test_split_k_stress).  The release is what costs: it writes back the XCD's whole dirty L2
             // (+80 us per launch measured), so it is not the default.
             __shared__ int s_last;
-            // layout [split][tile][wave][accumulator register 0..63][lane]: a wave-instruction writes / reads 256 contiguous bytes (in the
-            // [M][Cout] layout every lane of a dword access touched a cache line of its own: +130 us per launch), and the last
-            // arriver's lane (wave, lane) finds exactly its own elements at its own offset.  Same size: 256 x 128 floats per tile.
+            // layout [split][tile][wave][accumulator tile 0..15][lane][4]: one f32x4 accumulator per 16-byte transaction, 1 KiB
+            // contiguous per wave-instruction (in the [M][Cout] layout every lane of a dword access touched a cache line of its own:
+            // +130 us per launch; as dwords [register][lane] the hand-off took four times the vector-memory instructions), and the
+            // last arriver's lane (wave, lane) finds exactly its own elements at its own offset.  Same size: 256 x 128 floats per tile.
+            // Inline asm (the atomic builtins stop at 8 bytes) with the sc1 policy of the argument above on both sides; s_nop: the
+            // > 8-byte store-data hazard, which the hazard recognizer cannot see inside an asm statement.
             const int ntile = nblk / ksp;
-            auto pbase = [&](int sp) { return p.partial + 1024 + ((((int64_t)sp * ntile + t.tix) * 8 + wave) * 64) * 64 + lane; };     // [1024 counters][partials]
+            auto pbase = [&](int sp) { return p.partial + 1024 + ((((int64_t)sp * ntile + t.tix) * 8 + wave) * 64) * 64 + lane * 4; };     // [1024 counters][partials]
             {
                 float* pp = pbase(t.ks);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            __hip_atomic_store(pp + (i * 16 + j * 4 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 0" :: "v"(pp + i * 1024), "v"(acc[i][j]), "n"(j * 1024) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this lane's partial stores have been acknowledged ...
             __syncthreads();                         // ... and every lane's, before the workgroup's arrival is counted
@@ -526,26 +527,44 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             if (last) {
                 float cthis[16];
                 load_cadd(t, cthis);
+                // per split count a straight-line read-back: the loaded registers reach their wait untouched (the compiler does not
+                // know they are still being written, so no select or copy may sit between a load and the wait)
+                auto reduce = [&](auto ks_c) {
+                    constexpr int KS = decltype(ks_c)::value;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // two splits' loads of a pixel row at a time (32 in flight), then the adds in the fixed order split 0, 1, ...
+                    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cthis[j * 4], cthis[j * 4 + 1], cthis[j * 4 + 2], cthis[j * 4 + 3]};
-                    for (int s0 = 0; s0 < ksp; s0 += 2) {
-                        float tmp[2][16];
+                        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cthis[j * 4], cthis[j * 4 + 1], cthis[j * 4 + 2], cthis[j * 4 + 3]};
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const float* pp = pbase(s0 + u < ksp ? s0 + u : 0) + i * 16 * 64;
+                        for (int u0 = 0; u0 < KS; u0 += 2) {           // two splits at a time (32 registers in flight), adds in the order split 0, 1, ...
+                            constexpr int dummy = 0; (void)dummy;
+                            const bool two = u0 + 1 < KS;              // compile-time after unrolling
+                            f32x4_t tq[2][4];
 #pragma unroll
-                            for (int k = 0; k < 16; ++k)
-                                tmp[u][k] = s0 + u < ksp ? __hip_atomic_load(pp + k * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                            for (int u = 0; u < 2; ++u) {
+                                if (u == 1 && !two) break;
+                                const float* pp = pbase(u0 + u) + i * 4 * 256;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(tq[u][j]) : "v"(pp), "n"(j * 1024) : "memory");
+                            }
+                            if (two) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tq[0][0]), "+v"(tq[0][1]), "+v"(tq[0][2]), "+v"(tq[0][3]),
+                                                  "+v"(tq[1][0]), "+v"(tq[1][1]), "+v"(tq[1][2]), "+v"(tq[1][3]) :: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(tq[0][0]), "+v"(tq[0][1]), "+v"(tq[0][2]), "+v"(tq[0][3]) :: "memory");
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                if (u == 1 && !two) break;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) acc[i][j][r] += tq[u][j][r];
+                            }
                         }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + tmp[0][j * 4 + r]) + tmp[1][j * 4 + r];     // + 0.f past ksp: exact
                     }
-                }
+                };
+                if (ksp == 2) reduce(std::integral_constant<int, 2>{});
+                else if (ksp == 3) reduce(std::integral_constant<int, 3>{});
+                else reduce(std::integral_constant<int, 4>{});          // (nlc_conv_halo_ksplit: at most 4)
             } else {
                 parked = true; done = true;
             }
