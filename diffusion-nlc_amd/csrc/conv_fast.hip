@@ -96,24 +96,39 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     // split-K: blockIdx.y owns the channel blocks [cb0, cb1)
     const int cb0 = (int)(((int64_t)ncb_all * blockIdx.y) / p.ksplit), cb1 = (int)(((int64_t)ncb_all * (blockIdx.y + 1)) / p.ksplit);
 
-    // ---- per-row tap tables: input pixel index (within the whole tensor) and validity bit per tap
+    // ---- per-row tap tables: input pixel index (within the whole tensor) and validity bit per tap.  Launch-invariant divisors go
+    //      through host-computed multiply-shift constants, and a tap is (row r, column s): three row bases + three column offsets and
+    //      their validity per output pixel instead of nine independent (y, x, four compares, multiply) chains - the tables cost
+    //      7.3 k cycles of a 60 k-cycle small-map launch before the first DMA could be issued (tools/fast_stamps.py).
     int pix[4][TAPS];
     unsigned vmask[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + lr + 32 * i;
-        vmask[i] = 0;
-        int b = 0, oy = 0, ox = 0;
         const bool mv = m < p.M;
-        if (mv) { b = m / HWo; const int rem = m - b * HWo; oy = rem / p.Wout; ox = rem - oy * p.Wout; }
+        const int mm = mv ? m : 0;
+        const int b = p.div_hwo.div(mm);
+        const int rem = mm - b * HWo;
+        const int oy = p.div_wo.div(rem), ox = rem - oy * p.Wout;
+        const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+        const int sh = p.ups ? 1 : 0;
+        int rowbase[KW]; bool oky[KW]; int col[KW]; bool okx[KW];
+#pragma unroll
+        for (int r = 0; r < KW; ++r) {
+            const int iy = iy0 + r, ix = ix0 + r;
+            oky[r] = mv && (unsigned)iy < (unsigned)HL;
+            okx[r] = (unsigned)ix < (unsigned)WL;
+            rowbase[r] = (b * p.Hin + (iy >> sh)) * p.Win;
+            col[r] = ix >> sh;
+        }
+        unsigned vm = 0;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            int iy = oy * p.stride + t / KW - p.pad_t, ix = ox * p.stride + t % KW - p.pad_l;
-            const bool ok = mv && iy >= 0 && iy < HL && ix >= 0 && ix < WL;
-            if (p.ups) { iy >>= 1; ix >>= 1; }
-            pix[i][t] = ok ? (b * p.Hin + iy) * p.Win + ix : 0;
-            vmask[i] |= (ok ? 1u : 0u) << t;
+            const bool ok = oky[t / KW] && okx[t % KW];
+            pix[i][t] = ok ? rowbase[t / KW] + col[t % KW] : 0;
+            vm |= (ok ? 1u : 0u) << t;
         }
+        vmask[i] = vm;
     }
     const int64_t wrow = (int64_t)TAPS * p.Cin_pad * ES;
     // LDS row R = lr + 32 i of the weight tile receives output channel (R & 64) + ((R & 15) >> 2) * 16 + ((R >> 4) & 3) * 4
@@ -238,8 +253,22 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     [&]<int... d>(std::integer_sequence<int, d...>) {
         ((d < nsteps ? issue_ahead(d, cb0, std::integral_constant<int, 0>{}, std::integral_constant<int, d>{}) : (void)0), ...);
     }(std::make_integer_sequence<int, AHEAD>{});
+    // The bias slice of this lane is fetched here, behind the prologue's DMA, and pinned into registers before the k-loop: loaded in
+    // the epilogue it cost every workgroup one exposed memory round trip (~2 k cycles of a 55 k-cycle small-map launch).  Plain
+    // loads + an empty asm that consumes them: the compiler waits for them there itself (vmcnt(0) - once, in the prologue).
+    float cbias[16];
+    const bool bias_early = p.bias && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) && n0 + BN <= p.Cout;      // workgroup-uniform
+    if (bias_early) {
+        const float4* bp4 = reinterpret_cast<const float4*>(p.bias + n0 + (wave & 1) * 64 + (lane >> 4) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 b4 = bp4[q]; cbias[q * 4] = b4.x; cbias[q * 4 + 1] = b4.y; cbias[q * 4 + 2] = b4.z; cbias[q * 4 + 3] = b4.w; }
+    }
     if (nsteps >= AHEAD) dma_wait_n<8 * (AHEAD - 1)>(); else dma_wait_all();
     __syncthreads();
+    if (bias_early) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(cbias[k]));
+    }
     int kt = 0, cur = 0;
     for (int cb = cb0; cb < cb1; ++cb) {
         auto body = [&](auto tap_c) {
@@ -374,8 +403,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     constexpr int NCH = 16 / PER;
     // branch-free loads (clamped index, zero page for a missing bias): a per-element "if (in range) load" compiles to
     // load; s_waitcnt vmcnt(0) pairs, one full memory latency each
-    float cbias[16];
-    {
+    if (!bias_early) {
         const float* zf = reinterpret_cast<const float*>(g_zero_page);
         const float* bp = p.bias ? p.bias : zf;
         const int hb = p.bias ? 1 : 0, last = p.Cout - 1;
@@ -392,6 +420,18 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
             const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
             const float sc = p.out_scale;
             const int act = p.act;
+            // all residual chunks are requested before the first row is stored (the compiler keeps a row's loads behind the previous
+            // row's stores - it cannot see that `out` and `res` do not alias: four exposed memory latencies per tile)
+            uint4 rq0[4], rq1[4];
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = min(m0 + wm * 64 + i * 16 + fr, p.M - 1);
+                    const T* rp = reinterpret_cast<const T*>(p.res) + res_row_m(p, m) * p.Cout + n;
+                    rq0[i] = *reinterpret_cast<const uint4*>(rp);
+                    rq1[i] = *reinterpret_cast<const uint4*>(rp + 8);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + wm * 64 + i * 16 + fr;
@@ -402,8 +442,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg] + cbias[j * 4 + reg];
                 if (has_res) {
-                    const T* rp = reinterpret_cast<const T*>(p.res) + res_row_m(p, m) * p.Cout + n;
-                    const uint4 r0 = *reinterpret_cast<const uint4*>(rp), r1 = *reinterpret_cast<const uint4*>(rp + 8);
+                    const uint4 r0 = rq0[i], r1 = rq1[i];
                     float rr[16];
                     chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
 #pragma unroll
@@ -428,7 +467,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                     if (pix_stats) st16.zero();
                     st16.add_chunk<T>(0, pk0); st16.add_chunk<T>(1, pk1);
                     if (pix_stats) {     // [b][pixel][chunk][{sum, sumsq}], stats_P = Hout * Wout
-                        const int b = m / HWo;
+                        const int b = p.div_hwo.div(m);
                         st16.store(p.stats, (int64_t)b * p.stats_P + (m - b * HWo), p.Cout, n, p.stats_gran);
                     }
                 }
@@ -441,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         if (done) break;
         const int m = m0 + wm * 64 + i * 16 + fr;
         if (m >= p.M) continue;
-        const int b = m / HWo;
+        const int b = p.div_hwo.div(m);
         float v[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j)

@@ -274,6 +274,7 @@ static void fill_params(const nlc_conv_desc* d, KParams& p) {
     p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math;
     p.policy = d->policy; p.tuning = d->tuning;
     p.stats_gran = d->stats_granule == 4 ? 4 : 8;
+    p.div_hwo = FastDiv::make(d->Hout * d->Wout); p.div_wo = FastDiv::make(d->Wout);
 }
 
 static bool desc_sane(const nlc_conv_desc* d, int dtype) {

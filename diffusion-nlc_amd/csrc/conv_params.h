@@ -11,6 +11,25 @@ constexpr int NTHREADS = 256;
 constexpr int STAGE_BYTES = (BM + BN) * KB_BYTES;    // 32 KiB
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;           // 64 KiB -> 2 workgroups per CU
 
+// Division of a 31-bit index by a launch-invariant divisor: q = n / d as one 32 x 32 -> high-32 multiply and a shift
+// (Granlund-Montgomery, N = 31: l = ceil(log2 d), mul = ceil(2^(31 + l) / d) < 2^32, q = mulhi(n, mul) >> (l - 1); d = 1: q = n).
+// The constants are computed on the host (fill_params); a runtime division costs ~40 VALU each on this chip and the tile prologues
+// did eight of them per lane.
+struct FastDiv {
+    unsigned mul; int shr;      // shr < 0: d == 1
+    __host__ static FastDiv make(int d) {
+        FastDiv f{0u, -1};
+        if (d <= 1) return f;
+        int l = 0;
+        while ((1ll << l) < d) ++l;
+        const unsigned long long num = 1ull << (31 + l);
+        f.mul = (unsigned)((num + (unsigned)d - 1) / (unsigned)d);
+        f.shr = l - 1;
+        return f;
+    }
+    __device__ __forceinline__ int div(int n) const { return shr < 0 ? n : (int)(__umulhi((unsigned)n, mul) >> shr); }
+};
+
 struct KParams {
     const char* x0; const char* x1;
     int C0, C1, Ctot;
@@ -31,6 +50,7 @@ struct KParams {
     int res_ups;        // res is [B][Hout/2][Wout/2][Cout]: output pixel (y, x) adds res pixel (y >> 1, x >> 1) (nlc_conv_desc.res_upsample2x)
     int math;           // NLC_MATH_* (nlc_conv_desc.math): f32 tensors only; F16X3 = weights packed as (hi, lo) f16 halves
     int stats_gran;     // channels per chunk of `stats` (nlc_conv_desc.stats_granule): 8, or 4 for consumers whose groups are 4 channels wide
+    FastDiv div_hwo, div_wo;    // by Hout * Wout and by Wout (output row index -> image, y, x)
 };
 
 // ---- ride-along GroupNorm statistics of a lane's 16 consecutive output channels: (sum, sum of squares) of the STORED values per
@@ -102,8 +122,8 @@ __device__ __forceinline__ int64_t res_row(const KParams& p, int tb, int y, int 
 __device__ __forceinline__ int64_t res_row_m(const KParams& p, int64_t m) {
     if (!p.res_ups) return m;
     const int HWo = p.Hout * p.Wout;
-    const int b = (int)(m / HWo), rem = (int)(m - (int64_t)b * HWo);
-    const int y = rem / p.Wout, x = rem - y * p.Wout;
+    const int b = p.div_hwo.div((int)m), rem = (int)(m - (int64_t)b * HWo);           // (m < 2^31: dispatch)
+    const int y = p.div_wo.div(rem), x = rem - y * p.Wout;
     return ((int64_t)b * (p.Hout >> 1) + (y >> 1)) * (p.Wout >> 1) + (x >> 1);
 }
 
