@@ -597,7 +597,10 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     const int target = (p.tuning & 16384) ? 256 : 512;           // workgroups aimed at (A/B: bit 14 = one per CU)
     if (tiles >= target) return 1;
     int s = cdiv(target, tiles);
-    const int min_cb = k3 ? 2 : 8;                   // >= 18 (3x3) / 8 (1x1) k-steps per split (one channel block per split, up to 16
+    // >= 18 (3x3) / 8 (1x1) k-steps per split; a 3x3 launch that would otherwise put fewer than 128 workgroups on the chip goes down to
+    // one channel block (9 k-steps) per split (512 -> 512 @8x8, B = 8: 16 tiles x 4 -> x 8, 25.2 -> 22.8 us with the 16-byte hand-off;
+    // as a general rule it is slower: profiles/r03_summary.md section 5)
+    const int min_cb = k3 ? (tiles * (ncb / 2) < 128 ? 1 : 2) : 8;                   // (one channel block per split, up to 16
     if (s > ncb / min_cb) s = ncb / min_cb;          //  splits: measured slower, profiles/r03_summary.md section 5)
     if (s > 8) s = 8;                                // (the read-back in the kernel is instantiated for 2 ... 8)
     return s < 2 ? 1 : s;
