@@ -90,9 +90,14 @@ class HipModule:
     def _graph_call(self, fn, args, kwargs):
         self._require_gpu()
         items = list(args) + [kwargs[k] for k in sorted(kwargs)]
+        # (an input that carries ride-along GroupNorm statistics - ops.conv2d attaches them to its output - keeps them through the
+        #  static copy: the captured network must consume the same statistics an eager call would, not recompute them in another
+        #  summation order)
+        stats_of = lambda a: getattr(a, "_nlc_stats", None) if torch.is_tensor(a) else None
         key = (fn.__name__, self.compute_dtype, self.matmul, ops.CONV_POLICY, ops.CONV_TUNING, ops.FUSE_GN_CONV, ops.FUSE_GN_POOL,
                ops.FUSED_GN_STATS, len(args), tuple(sorted(kwargs)),
-               tuple((tuple(a.shape), a.dtype) if torch.is_tensor(a) else a for a in items))
+               tuple((tuple(a.shape), a.dtype, None if stats_of(a) is None else tuple(stats_of(a).shape)) if torch.is_tensor(a) else a
+                     for a in items))
         cache = self.__dict__.setdefault("_graphs", {})
         ent = cache.get(key)
         with torch.cuda.device(self.device):
@@ -106,6 +111,9 @@ class HipModule:
                 if cs is None:
                     cs = self.__dict__["_capture_stream"] = torch.cuda.Stream(device=self.device)
                 static = [a.clone() if torch.is_tensor(a) else a for a in items]
+                for a, st in zip(items, static):
+                    if stats_of(a) is not None:
+                        st._nlc_stats = stats_of(a).clone()
                 s_args = static[:len(args)]
                 s_kwargs = dict(zip(sorted(kwargs), static[len(args):]))
                 cs.wait_stream(torch.cuda.current_stream())
@@ -120,6 +128,8 @@ class HipModule:
             for a, st in zip(items, static):
                 if torch.is_tensor(a) and a.data_ptr() != st.data_ptr():
                     st.copy_(a)
+                    if stats_of(a) is not None:
+                        st._nlc_stats.copy_(stats_of(a))
             g.replay()
         return out
 

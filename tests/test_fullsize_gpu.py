@@ -158,7 +158,11 @@ def test_adm256_16bit_first_step_against_the_oracle_at_full_size(adm256, adm256_
 # Measured (round 3): cfg 4 f32 5.4e-4, f32x3 2.7e-4 (L-inf); bf16 final RMS 0.074, first-x0 RMS 0.030, sigma 9.5e-4; f16 final RMS
 # 3.2e-3 ... 6.9e-2 (the two dispatches part ways at a clamp within three timesteps), first-x0 RMS 4.1e-3, sigma 1.8e-4.
 # cfg 3 f32 9.8e-6, f32x3 1.1e-5 (L-inf); bf16 RMS 5.4e-3, f16 6.8e-4 (sample RMS 1.22).
-CELEBA_GATES = {"f32": 1e-3, "f32x3": 1e-3, "bf16": (0.11, 0.045, 2e-3), "f16": (0.11, 6.5e-3, 5e-4)}
+# The corrected sigma of ONE image is one draw of a scalar whose 16-bit error spreads 5x from image to image and from one summation
+# order to the next (profiles/r03_sigma_precision.txt: bf16 0.6 ... 3.0e-3, f16 0.4 ... 3.2e-4 over six images; this test's own value
+# moved 9.5e-4 -> 2.2e-3 when the split-K hand-off and the statistics reduction changed their summation order): its gate is the top of
+# that spread x 1.5, not 1.5 x one draw.
+CELEBA_GATES = {"f32": 1e-3, "f32x3": 1e-3, "bf16": (0.11, 0.045, 4.5e-3), "f16": (0.11, 6.5e-3, 5e-4)}
 EDM_GATES = {"f32": 1e-3, "f32x3": 1e-3, "bf16": 8e-3, "f16": 1.1e-3}
 
 
