@@ -201,7 +201,8 @@ class AdmWorkload:
         d = x0s[n - 1].double() - tr["x0"][n - 1].double()
         srel = [float(((sig[i].double().view(-1) - tr["sigma"][i].double().view(-1)).abs() / tr["sigma"][i].double().view(-1)).max()) for i in range(n)]
         return {"dtype": dtype_name, "timesteps": n, "linf": per_step[-1], "rms": float(d.pow(2).mean().sqrt()),
-                "sigma_rel": srel[-1], "linf_first_timestep": per_step[0], "linf_max_over_timesteps": max(per_step),
+                "sigma_rel": srel[-1], "linf_first_timestep": per_step[0], "sigma_rel_first_timestep": srel[0],
+                "linf_max_over_timesteps": max(per_step),
                 "sigma_rel_max_over_timesteps": max(srel),
                 "what": "HIP path at B=1 on the cpu_baseline leg's seeded x_T vs the CPU oracle (f32), clipped x0 estimate after each of "
                         f"the first {n} DDIM+NLC timesteps; values are for timestep {n} unless named otherwise"}
