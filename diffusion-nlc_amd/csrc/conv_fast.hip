@@ -107,6 +107,13 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         const int m = m0 + lr + 32 * i;
         const bool mv = m < p.M;
         const int mm = mv ? m : 0;
+        if constexpr (TAPS == 1) {
+            if (!p.ups) {                            // unpadded stride-1 1x1: input pixel = output pixel, no (image, y, x) needed
+                pix[i][0] = mm;
+                vmask[i] = mv ? 1u : 0u;
+                continue;
+            }
+        }
         const int b = p.div_hwo.div(mm);
         const int rem = mm - b * HWo;
         const int oy = p.div_wo.div(rem), ox = rem - oy * p.Wout;
