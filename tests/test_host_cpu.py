@@ -106,3 +106,23 @@ def test_continuous_t_and_redesigned_schedules_match_reference():
     assert s.continuous_t and s.sampling_sigmas.dtype == g["sampling_sigmas"].dtype == torch.float64
     assert torch.equal(s.sampling_sigmas, g["sampling_sigmas"])
     assert torch.equal(s.timesteps, g["timesteps"])
+
+
+def test_multiply_shift_division_constants_are_exact():
+    """conv_params.h: FastDiv (host side fills mul / shr per launch, the kernels compute q = mulhi(n, mul) >> shr).  Restated here:
+    l = ceil(log2 d), mul = ceil(2^(31 + l) / d) < 2^32, q = (n * mul >> 32) >> (l - 1) must equal n // d for every 31-bit n
+    (Granlund-Montgomery, N = 31); d = 1 is the kernels' special case."""
+    import random
+    rnd = random.Random(7)
+    ds = list(range(2, 300)) + [2 ** k for k in range(1, 31)] + [2 ** k + 1 for k in range(1, 30)] + [2 ** k - 1 for k in range(2, 31)] + \
+         [rnd.randrange(2, 2 ** 31) for _ in range(500)] + [65536 * 16, 256 * 256, 1023, 1025]
+    for d in ds:
+        l = (d - 1).bit_length()
+        mul = ((1 << (31 + l)) + d - 1) // d
+        assert mul < (1 << 32), d
+        shr = l - 1
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, (1 << 31) - d, ((1 << 31) - 1) // d * d, ((1 << 31) - 1) // d * d - 1] + \
+             [rnd.randrange(0, 1 << 31) for _ in range(64)]
+        for n in ns:
+            if 0 <= n < (1 << 31):
+                assert ((n * mul) >> 32) >> shr == n // d, (n, d)

@@ -97,6 +97,13 @@ CONV_CASES = [
     dict(B=2, Cin=256, H=32, W=32, Cout=128, k=3, res=True, scale=math.sqrt(0.5)),
     dict(B=4, Cin=64, H=32, W=32, Cout=128, k=3, act="silu"),
     dict(B=2, Cin=128, H=16, W=16, Cout=256, k=3, ups=True, res=True),                 # fused upsample outside the halo kernel
+    # widths / areas that are no powers of two: the tap tables divide by Wout and Hout*Wout through host-computed multiply-shift
+    # constants (conv_params.h: FastDiv), tiles straddle image boundaries, strided and upsampled variants
+    dict(B=5, Cin=64, H=11, W=13, Cout=128, k=3, res=True),
+    dict(B=3, Cin=64, H=10, W=6, Cout=64, k=3, stride=2, pad=1),
+    dict(B=7, Cin=128, H=5, W=3, Cout=128, k=3, ups=True),
+    dict(B=33, Cin=64, H=3, W=1, Cout=64, k=3),                      # Wout = 1: the d = 1 special case
+    dict(B=3, Cin=64, H=100, W=1, Cout=64, k=1, res=True),
 ]
 
 
