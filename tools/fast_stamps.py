@@ -43,7 +43,7 @@ def patched_source() -> str:
     sub("    const int64_t wrow = (int64_t)TAPS * p.Cin_pad * ES;",
         "    asm volatile(\"\" :: \"v\"(pix[3][TAPS - 1]), \"v\"(vmask[3]));\n    st[0] = now() - st0;\n"
         "    const int64_t wrow = (int64_t)TAPS * p.Cin_pad * ES;")
-    sub("    __syncthreads();\n    int kt = 0, cur = 0;", "    __syncthreads();\n    st[1] = now() - st0;\n    int kt = 0, cur = 0;")
+    sub("    int kt = 0, cur = 0;", "    st[1] = now() - st0;\n    int kt = 0, cur = 0;")
     sub("    const int n = n0 + wn * 64 + fq * 16;\n    const bool all16 = n + 16 <= p.Cout;",
         "    st[2] = now() - st0;\n    const int n = n0 + wn * 64 + fq * 16;\n    const bool all16 = n + 16 <= p.Cout;")
     sub("        __syncthreads();                                             // ... and every lane's, before the arrival is counted",
@@ -54,6 +54,9 @@ def patched_source() -> str:
     sub("    if (n >= p.Cout) return;\n    const bool pix_stats",
         "    asm volatile(\"\" :: \"v\"(acc[3][3][3]), \"v\"(acc[0][0][0]));\n    st[5] = now() - st0; st[9] = 1;\n"
         "    if (n >= p.Cout) { flush(); return; }\n    const bool pix_stats")
+    sub("    Stat16 st16;                                                // ride-along GroupNorm statistics: this lane's 16 channels, 4 pixels",
+        "    st[7] = now() - st0;\n    Stat16 st16;                                                // ride-along GroupNorm statistics: this lane's 16 channels, 4 pixels")
+    sub("            done = true;\n", "            st[8] = now() - st0;\n            done = true;\n")
     # kernel end: last closing brace of the kernel = before 'template <typename T, int TAPS, int STAGES, bool X3 = false>\nint launch_fast'
     sub("}\n\ntemplate <typename T, int TAPS, int STAGES, bool X3 = false>\nint launch_fast",
         "    st[6] = now() - st0;\n    flush();\n}\n\ntemplate <typename T, int TAPS, int STAGES, bool X3 = false>\nint launch_fast")
@@ -113,6 +116,8 @@ def run(H=8, cin=512, cout=512, batch=8, k=3):
     la = a[a[:, 9] > 0]
     if len(la):
         print(f"   {'last arriver: partials read':30s} median {np.median(la[:, 5]):9.0f} cycles")
+        print(f"   {'last arriver: bias ready':30s} median {np.median(la[:, 7]):9.0f} cycles")
+        print(f"   {'last arriver: rows stored':30s} median {np.median(la[:, 8]):9.0f} cycles")
         print(f"   {'last arriver: end':30s} median {np.median(la[:, 6]):9.0f} cycles  (max {la[:, 6].max():.0f})")
         end_ns = (la[:, 10] - a[:, 10].min()) * 10.0
         print("   last arrivers enter at (ns after the first workgroup): median %.0f" % np.median(end_ns))
