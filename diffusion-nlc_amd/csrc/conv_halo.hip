@@ -537,7 +537,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cthis[j * 4], cthis[j * 4 + 1], cthis[j * 4 + 2], cthis[j * 4 + 3]};
 #pragma unroll
                         for (int u0 = 0; u0 < KS; u0 += 2) {           // two splits at a time (32 registers in flight), adds in the order split 0, 1, ...
-                            constexpr int dummy = 0; (void)dummy;
                             const bool two = u0 + 1 < KS;              // compile-time after unrolling
                             f32x4_t tq[2][4];
 #pragma unroll
