@@ -640,6 +640,59 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 inited = true;
             }
         }
+        if constexpr (!FOLD) {
+            // f32 tensors (exact-f32 and split-f16 math), whole N-tile, NHWC, no activation, 16-byte-aligned bias / embedding: vector
+            // loads of the bias and embedding slices and of all sixteen residual chunks up front, the reference's order of additions
+            // (conv sum, + bias, + embedding, + residual, x scale), four 16-byte stores per row.  The general path below did 32 scalar
+            // loads with clamps per tile and kept every row's residual loads behind the previous row's stores: 11-15 k cycles of a
+            // 167 k-cycle tile of the split-f16 kernel (tools/halo_stamps.py --x3).
+            const bool al16 = p.bias && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
+                              (!p.emb || ((reinterpret_cast<uintptr_t>(p.emb) & 15) == 0 && (p.emb_stride & 3) == 0));
+            if (!done && al16 && vec_ok && t.n0 + BN <= p.Cout && p.out_mode == NLC_OUT_NHWC && p.act == NLC_ACT_NONE) {      // workgroup-uniform
+                const float4* bp4 = reinterpret_cast<const float4*>(p.bias + n);
+                float4 bq[4], eq4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bq[q] = bp4[q];
+                const bool has_emb = p.emb != nullptr, has_res = p.res != nullptr;
+                if (has_emb) {
+                    const float4* ep4 = reinterpret_cast<const float4*>(p.emb + (int64_t)t.tb * p.emb_stride + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) eq4[q] = ep4[q];
+                }
+                const int64_t m0 = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4) * p.Wout + t.x0 + fr;
+                const int64_t rstride = (int64_t)p.Wout * p.Cout;
+                const float sc = p.out_scale;
+                float* const op0 = reinterpret_cast<float*>(p.out) + m0 * p.Cout + n;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                        // two rows at a time: eight residual chunks in flight (32 registers)
+                    float4 rq[2][4];
+                    if (has_res) {
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const int i = 2 * h + ii;
+                            const float4* rp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) +
+                                                                                res_row(p, t.tb, t.y0 + wm * 4 + i, t.x0 + fr) * p.Cout + n);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rq[ii][q] = rp[q];
+                        }
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int i = 2 * h + ii;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float4 v = float4{acc[i][q][0], acc[i][q][1], acc[i][q][2], acc[i][q][3]};
+                            v.x += bq[q].x; v.y += bq[q].y; v.z += bq[q].z; v.w += bq[q].w;
+                            if (has_emb) { v.x += eq4[q].x; v.y += eq4[q].y; v.z += eq4[q].z; v.w += eq4[q].w; }
+                            if (has_res) { v.x += rq[ii][q].x; v.y += rq[ii][q].y; v.z += rq[ii][q].z; v.w += rq[ii][q].w; }
+                            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                            *reinterpret_cast<float4*>(op0 + i * rstride + q * 4) = v;
+                        }
+                    }
+                }
+                done = true;
+            }
+        }
         if (!done && n < p.Cout) {
             const bool full = vec_ok && (n + 16 <= p.Cout);
             constexpr int NCH = 16 / PER;

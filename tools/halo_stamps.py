@@ -98,7 +98,7 @@ def build():
     print("built", OUT)
 
 
-def run(H=256, cin=256, cout=256, res=False):
+def run(H=256, cin=256, cout=256, res=False, x3=False):
     os.environ["NLC_HIP_LIB"] = str(OUT)
     sys.path.insert(0, str(ROOT))
     import math
@@ -107,10 +107,11 @@ def run(H=256, cin=256, cout=256, res=False):
     from diffusion_nlc_amd import _ext, ops
     lib = _ext.load()          # the ctypes handle of the patched library (NLC_HIP_LIB)
     dev = torch.device("cuda:0")
-    x = torch.randn(16, H, H, cin, device=dev).bfloat16()
+    dt = torch.float32 if x3 else torch.bfloat16             # --x3: the f32 tensors / split-f16 math instantiation
+    x = torch.randn(16, H, H, cin, device=dev).to(dt)
     w = torch.randn(cout, cin, 3, 3) / math.sqrt(cin * 9)
-    pw = ops.pack_conv(w, torch.zeros(cout), torch.bfloat16, dev)
-    r = torch.randn(16, H, H, cout, device=dev).bfloat16() if res else None
+    pw = ops.pack_conv(w, torch.zeros(cout), dt, dev, math="f16x3" if x3 else "native")
+    r = torch.randn(16, H, H, cout, device=dev).to(dt) if res else None
     for _ in range(5):
         ops.conv2d(x, pw, res=r)
     torch.cuda.synchronize()
@@ -139,4 +140,4 @@ if __name__ == "__main__":
         build()
     else:
         a = [int(v) for v in sys.argv[2:5]]
-        run(*a, res="--res" in sys.argv)
+        run(*a, res="--res" in sys.argv, x3="--x3" in sys.argv)
