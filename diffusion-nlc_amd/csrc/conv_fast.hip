@@ -329,10 +329,10 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    // (s_nop: a store of more than 8 bytes needs one wait state before a VALU write of its data registers - the
+                    // (s_nop 1: a store of more than 8 bytes needs wait states before a VALU write of its data registers (two on this target) - the
                     //  hazard recognizer inserts it for the compiler's own stores but cannot see into an asm statement; without it
                     //  the next tile's v_accvgpr_read overwrote dword 0 of the data for the last lanes still being read)
-                    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 0" :: "v"(pp + i * 1024), "v"(acc[i][j]), "n"(j * 1024) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" :: "v"(pp + i * 1024), "v"(acc[i][j]), "n"(j * 1024) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this lane's partial stores have been acknowledged ...
         __syncthreads();                                             // ... and every lane's, before the arrival is counted

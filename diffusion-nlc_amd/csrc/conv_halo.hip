@@ -507,7 +507,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 0" :: "v"(pp + i * 1024), "v"(acc[i][j]), "n"(j * 1024) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1\n\ts_nop 1" :: "v"(pp + i * 1024), "v"(acc[i][j]), "n"(j * 1024) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this lane's partial stores have been acknowledged ...
             __syncthreads();                         // ... and every lane's, before the workgroup's arrival is counted
