@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -25,7 +26,7 @@ import torch
 
 from . import _ext, ops
 from ._ext import NlcError, check
-from .experiments import ImageExperiment, StackedRandomGenerator
+from .experiments import ImageExperiment, StackedRandomGenerator, save_image
 
 
 def _s():
@@ -238,39 +239,60 @@ class EDMImageExperiment(ImageExperiment):
         return x_next
 
     @torch.no_grad()
-    def evaluate_edm(self, n_samples, images_dir=None, gen=None, style="base,base", norm_eps="000", refine_prior_sigma=False,
-                     microbatch=-1, sigma_scheduler="EDM", eps_ratio=0.5, eps_scale=1.0, use_second_order=True, save_fn=None):
-        """:922-961: per-batch host generators seeded 0..n-1 (StackedRandomGenerator), samples mapped to [0,1].
-        PNG writing / FID are optional side effects: ``save_fn(sample01, batch_index)`` if given.
+    def evaluate_edm(self, n_samples, images_dir, gen=None, style="base,base", norm_eps="000", refine_prior_sigma=False,
+                     microbatch=-1, sigma_scheduler="EDM", eps_ratio=0.5, eps_scale=1.0, use_second_order=True,
+                     return_samples=False, save_images=True):
+        """:922-961, same positional arguments and the same return value: ``log_dict`` (``{'fid': ...}``).
 
-        Under a launcher (one process per GPU, shard.init_from_env) rank r samples batches r, r+W, ...: every sample owns its
-        generator (seed = global sample index), so nothing has to be replayed; one all-gather collects the samples in order on
-        every rank, and rank 0 runs ``save_fn`` / FID."""
+        Per-batch host generators seeded with the global sample indices (StackedRandomGenerator), samples mapped to [0,1] and
+        written as ``{rank:02}-{batch:05}-{j:03}.png`` into ``images_dir``; a batch whose PNGs all exist is skipped (:935-943);
+        FID over ``images_dir`` (NaN without pytorch_fid).  ``gen`` is accepted and ignored, as upstream (:933 overwrites it).
+        Extensions (keywords only): ``return_samples=True`` returns ``(log_dict, samples)``; the [0,1] samples of the batches
+        this call sampled are also left in ``self.last_samples`` (float64, in batch order); ``save_images=False`` writes no PNGs
+        (``images_dir`` may then be None).
+
+        Under a launcher (one process per GPU, shard.init_from_env) rank r samples the to-do batches r, r+W, ...: every sample
+        owns its generator (seed = global sample index), so nothing has to be replayed; one all-gather collects the samples in
+        order on every rank, and rank 0 writes the PNGs (prefix 00, as the single-process run) and computes FID."""
         from . import shard
         world, rank = shard.world_rank()
         batch_size = microbatch if microbatch > 0 else self.batch_size
         if n_samples % batch_size:
             raise ValueError("n_samples must be a multiple of batch_size (the reference asserts this at :77, SURVEY.md §9)")
-        seeds = torch.arange(n_samples).tensor_split(n_samples // batch_size)
+        n_batches = n_samples // batch_size
+        seeds = torch.arange(n_samples).tensor_split(n_batches)
+        write = bool(save_images and images_dir)
+        paths = [[os.path.join(images_dir, f"{0:02}-{i:05}-{j:03}.png") for j in range(batch_size)] if write else []
+                 for i in range(n_batches)]
+        skip = shard.broadcast_object([bool(write and all(os.path.exists(p) for p in pp)) for pp in paths])
+        for i in range(n_batches):
+            if skip[i]:
+                print("skip images for:", f"{0:02}-{i:05}-({0:03}~{batch_size - 1:03}).png")
+        todo = [i for i in range(n_batches) if not skip[i]]
         outs = []
-        for i, sd in enumerate(seeds):
-            if i % world != rank:
+        for k, i in enumerate(todo):
+            if k % world != rank:
                 continue
-            g = StackedRandomGenerator(self.device, sd)
+            g = StackedRandomGenerator(self.device, seeds[i])
             x = self.edm_sampler(shape=(batch_size,) + self.data_shape, gen=g, style=style, norm_eps=norm_eps,
                                  refine_prior_sigma=refine_prior_sigma, sigma_scheduler=sigma_scheduler, eps_ratio=eps_ratio,
                                  eps_scale=eps_scale, use_second_order=use_second_order)
             sample = x.add(1).div(2).clamp(0, 1)
-            if save_fn is not None and world == 1:
-                save_fn(sample, i)
+            if write and world == 1:
+                for img, p in zip(sample, paths[i]):
+                    save_image(img, p)
             outs.append(sample)
+            print(f"done batches:{i}/{n_batches}")
         if world > 1:
             local = torch.stack(outs) if outs else torch.empty((0, batch_size) + tuple(self.data_shape), device=self.device, dtype=torch.float64)
-            allx = shard.gather_samples(local, len(seeds), world, rank)
-            if save_fn is not None and rank == 0:
-                for i in range(len(seeds)):
-                    save_fn(allx[i], i)
+            allx = shard.gather_samples(local, len(todo), world, rank)
+            if write and rank == 0:
+                for k, i in enumerate(todo):
+                    for img, p in zip(allx[k], paths[i]):
+                        save_image(img, p)
             shard.barrier()
             outs = list(allx)
-        fid = self.fid_fn(images_dir) if (self.fid_fn is not None and images_dir and rank == 0) else float("nan")
-        return {"fid": fid}, torch.cat(outs)
+        self.last_samples = torch.cat(outs) if outs else torch.empty((0,) + tuple(self.data_shape), device=self.device, dtype=torch.float64)
+        fid = self.fid_fn(images_dir) if (self.fid_fn is not None and images_dir and rank == 0) else (float("nan") if rank == 0 else 0.0)
+        log_dict = {"fid": fid}
+        return (log_dict, self.last_samples) if return_samples else log_dict

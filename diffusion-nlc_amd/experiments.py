@@ -46,6 +46,18 @@ class StackedRandomGenerator:
         return self.randn(input.shape, dtype=input.dtype)
 
 
+def save_image(img, path):
+    """torchvision.utils.save_image for one [C,H,W] image in [0,1] (what the reference calls per sample, src/experiments.py:40,950;
+    image_sample.py:15): round-to-nearest 8-bit PNG through PIL.  A side effect outside the sampling path; without PIL nothing
+    is written."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    arr = img.detach().to("cpu", torch.float32).mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    Image.fromarray(arr[..., 0] if arr.shape[-1] == 1 else arr).save(path)
+
+
 class ExperimentDiffusion:
     def __init__(self, model, scheduler, batch_size, data_shape, save_folder, seed=0, device="cpu", dist_train=0,
                  time_shift=0):

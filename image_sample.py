@@ -207,12 +207,8 @@ def get_args(argv=None):
 
 
 def save_png(img, path):
-    try:
-        from PIL import Image
-    except ImportError:
-        return
-    arr = (img.clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
-    Image.fromarray(arr).save(path)
+    from diffusion_nlc_amd.experiments import save_image
+    save_image(img, path)
 
 
 @torch.no_grad()

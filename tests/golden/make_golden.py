@@ -440,6 +440,84 @@ def gen_classcond():
     save("net_adm_tiny_cc", x=x, t=t, y=y, out=out, feat=feat, r=sig(feat))
 
 
+def gen_cli_flags():
+    """The command lines of the reference's two entry points as DATA: for image_sample.py and edm_image_sample.py, every
+    flag of the reference's own ArgumentParser (name, default, type, choices), captured from the parser object the reference's
+    get_args() builds (parse_args is intercepted; nothing of the reference's text is stored), plus - for edm_image_sample.py -
+    the namespace its get_args() RETURNS for each --config when run in a scratch directory holding a minimal
+    results/<config>/<folder>/args.json and store/config/<config>.yml (that pins get_default's per-config presets and the
+    derived result_dir / test_dir paths).  -> tests/golden/cli_flags.json"""
+    import importlib
+    import os
+    import tempfile
+    for name, attrs in (("basicsr", {}), ("basicsr.metrics", {}), ("basicsr.metrics.psnr_ssim", dict(calculate_ssim=None)),
+                        ("datasets", dict(get_dataset=None)), ("joblib", {}), ("requests", {})):
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:                                     # noqa: BLE001
+                m = types.ModuleType(name)
+                m.__dict__.update(attrs)
+                sys.modules[name] = m
+
+    class _Captured(Exception):
+        pass
+
+    def capture(get_args):
+        orig = argparse.ArgumentParser.parse_args
+        box = {}
+
+        def fake(self, *a, **k):
+            box["parser"] = self
+            raise _Captured
+
+        argparse.ArgumentParser.parse_args = fake
+        try:
+            get_args()
+        except _Captured:
+            pass
+        finally:
+            argparse.ArgumentParser.parse_args = orig
+        flags = {}
+        for act in box["parser"]._actions:
+            if not act.option_strings or act.dest == "help":
+                continue
+            flags[act.option_strings[0]] = dict(default=act.default, type=getattr(act.type, "__name__", None),
+                                                choices=list(act.choices) if act.choices is not None else None)
+        return flags
+
+    import image_sample as RIS
+    import edm_image_sample as RES
+    out = dict(image_sample=capture(RIS.get_args), edm_image_sample=capture(RES.get_args), _meta=META)
+
+    # the reference's get_args() run for real, per config, in a scratch tree
+    presets = {}
+    cwd, argv = os.getcwd(), sys.argv
+    saved = dict(load_eps="eps_from_args_json.pkl", fid_target="fid_from_args_json.npz", sigma_block=3, sigma_dropout=0.25,
+                 use_sigma_fp16=False, feat_layer=2)
+    try:
+        for cfg in ("cifar10", "ffhq"):
+            with tempfile.TemporaryDirectory() as td:
+                os.makedirs(os.path.join(td, "results", cfg, "6"))
+                os.makedirs(os.path.join(td, "store", "config"))
+                with open(os.path.join(td, "results", cfg, "6", "args.json"), "w") as f:
+                    json.dump(saved, f)
+                with open(os.path.join(td, "store", "config", cfg + ".yml"), "w") as f:
+                    f.write("model:\n  img_resolution: 32\ndata:\n  channels: 3\n  image_size: 32\n")
+                os.chdir(td)
+                sys.argv = ["edm_image_sample.py", "--config", cfg, "--sampler", "euler", "--start_sigma", "70", "--end_sigma", "0.01"]
+                a, c = RES.get_args()
+                presets[cfg] = dict(args={k: v for k, v in sorted(vars(a).items())},
+                                    model={k: v for k, v in sorted(vars(c.model).items())})
+    finally:
+        os.chdir(cwd)
+        sys.argv = argv
+    out["edm_get_args"] = dict(saved_args_json=saved, argv=["--sampler", "euler", "--start_sigma", "70", "--end_sigma", "0.01"],
+                               result=presets)
+    (HERE / "cli_flags.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+    print("wrote cli_flags.json", {k: len(v) for k, v in out.items() if k.endswith("sample")})
+
+
 def main():
     _stub_missing_modules()
     torch.manual_seed(0)
@@ -451,7 +529,13 @@ def main():
     gen_inpaint(models)
     gen_project(models)
     gen_classcond()
+    gen_cli_flags()
 
 
 if __name__ == "__main__":
-    main()
+    if "--only-cli" in sys.argv:               # regenerate cli_flags.json alone (seconds)
+        sys.argv.remove("--only-cli")
+        _stub_missing_modules()
+        gen_cli_flags()
+    else:
+        main()

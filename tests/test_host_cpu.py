@@ -126,3 +126,66 @@ def test_multiply_shift_division_constants_are_exact():
         for n in ns:
             if 0 <= n < (1 << 31):
                 assert ((n * mul) >> 32) >> shr == n // d, (n, d)
+
+
+# ---- command lines of the two entry points vs the reference's own parsers (tests/golden/cli_flags.json) -------------------
+# The ONLY tolerated difference: the default of --device.  The reference hard-codes its authors' card index (cuda:1 / cuda:5,
+# image_sample.py:80, edm_image_sample.py:36), which does not exist on a one-GPU box; both entry points default to cuda:0.
+CLI_DEFAULT_WAIVERS = {"--device"}
+
+
+def _cli_flags(parser):
+    return {a.option_strings[0]: dict(default=a.default, type=getattr(a.type, "__name__", None),
+                                      choices=list(a.choices) if a.choices is not None else None)
+            for a in parser._actions if a.option_strings and a.dest != "help"}
+
+
+@pytest.mark.parametrize("cli", ["image_sample", "edm_image_sample"])
+def test_cli_flags_match_reference(cli):
+    """Every flag of the reference's parser exists here with the same default, type and choices; flags that exist only here are
+    the documented extensions."""
+    import importlib
+    import json
+    import math
+    ref = json.loads((ROOT / "tests" / "golden" / "cli_flags.json").read_text())[cli]
+    mod = importlib.import_module(cli)
+    got = _cli_flags(mod.build_parser())
+    missing = sorted(set(ref) - set(got))
+    assert not missing, f"{cli}.py lacks reference flags {missing}"
+    for flag, r in ref.items():
+        g = got[flag]
+        assert g["type"] == r["type"], (flag, g, r)
+        assert g["choices"] == r["choices"], (flag, g, r)
+        if flag in CLI_DEFAULT_WAIVERS:
+            continue
+        assert g["default"] == r["default"] and type(g["default"]) is type(r["default"]), (flag, g, r)
+    extensions = {"image_sample": {"--synthetic", "--return_log", "--save_png", "--precision"},
+                  "edm_image_sample": {"--synthetic", "--dtype", "--rho", "--S_churn", "--S_min", "--S_max", "--S_noise", "--save_png"}}[cli]
+    assert set(got) - set(ref) == extensions
+    for flag in extensions:                      # an extension left at its default must not change the reference's behaviour
+        d = got[flag]["default"]
+        assert d in (None, "", 0, 1, 7, "f32") or (isinstance(d, float) and math.isinf(d)), (flag, d)
+
+
+@pytest.mark.parametrize("cfg", ["cifar10", "ffhq"])
+def test_edm_get_args_matches_reference(cfg, tmp_path, monkeypatch):
+    """edm_image_sample.get_args() on the reference's own invocation line, in a scratch tree with the two files it reads, returns
+    the namespace the reference's get_args() returned (recorded by make_golden.py): derived paths, the values taken from the
+    training run's args.json, get_default's per-config norm bounds (ffhq: norm_max 102.0 + its checkpoint / FID paths)."""
+    import json
+    import edm_image_sample
+    fx = json.loads((ROOT / "tests" / "golden" / "cli_flags.json").read_text())["edm_get_args"]
+    (tmp_path / "results" / cfg / "6").mkdir(parents=True)
+    (tmp_path / "store" / "config").mkdir(parents=True)
+    (tmp_path / "results" / cfg / "6" / "args.json").write_text(json.dumps(fx["saved_args_json"]))
+    (tmp_path / "store" / "config" / f"{cfg}.yml").write_text("model:\n  img_resolution: 32\ndata:\n  channels: 3\n  image_size: 32\n")
+    monkeypatch.chdir(tmp_path)
+    args, config = edm_image_sample.get_args(["--config", cfg] + fx["argv"])
+    want = fx["result"][cfg]
+    got = vars(args)
+    for k, v in want["args"].items():
+        if k == "device":
+            continue
+        assert k in got and got[k] == v and type(got[k]) is type(v), (k, got.get(k), v)
+    assert vars(config.model) == want["model"]
+    assert (config.data.channels, config.data.image_size) == (3, 32)

@@ -145,11 +145,11 @@ def test_edm_evaluate_runs_and_is_deterministic():
     exp = EDMImageExperiment(eps, None, batch_size=2, data_shape=(3, 32, 32), seed=0, device="cuda:0", num_timesteps=4)
     exp.set_model(eps, sig, learn_epsvar=False)
     exp.set_norm_maxmin(0.0, 54.63)
-    _, a = exp.evaluate_edm(4, style="pred_partial,pred", norm_eps="000")
-    _, b = exp.evaluate_edm(4, style="pred_partial,pred", norm_eps="000")
+    _, a = exp.evaluate_edm(4, None, style="pred_partial,pred", norm_eps="000", return_samples=True)
+    _, b = exp.evaluate_edm(4, None, style="pred_partial,pred", norm_eps="000", return_samples=True)
     assert a.shape == (4, 3, 32, 32) and torch.equal(a, b) and a.min() >= 0 and a.max() <= 1
     with pytest.raises(ValueError):
-        exp.evaluate_edm(3)
+        exp.evaluate_edm(3, None)
 
 
 def test_inpainting_operator_and_constrained_loop():

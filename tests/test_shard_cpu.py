@@ -163,42 +163,58 @@ def test_evaluate_unconstraint_two_ranks_equal_single_process(tmp_path, noisy_st
     assert not torch.equal(torch.load(two / "00-00004-000.png"), torch.load(two / "00-00000-000.png"))
 
 
-def _edm_worker(rank, world, port, q):
+def _edm_worker(rank, world, port, q, images_dir):
     import types
     from diffusion_nlc_amd.experiments import EDMImageExperiment
+    from diffusion_nlc_amd import edm_experiment
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
         shard.init_from_env("gloo")
-    saved = []
+    edm_experiment.save_image = lambda img, path: torch.save(img.clone(), path)          # "PNG" = the exact tensor
     fake = types.SimpleNamespace(batch_size=2, data_shape=(3, 4, 4), device="cpu", fid_fn=None,
                                  edm_sampler=lambda shape, gen=None, **kw: gen.randn(shape, dtype=torch.float64) * 0.4)
-    _, samples = EDMImageExperiment.evaluate_edm(fake, 10, save_fn=lambda s, i: saved.append((i, s.clone())))
+    log, samples = EDMImageExperiment.evaluate_edm(fake, 10, images_dir, return_samples=True)
+    assert set(log) == {"fid"}
     if rank == 0:
-        q.put((samples.numpy(), [i for i, _ in saved]))
+        q.put(samples.numpy())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def test_evaluate_edm_two_ranks_equal_single_process():
-    """EDMImageExperiment.evaluate_edm under WORLD_SIZE=2: per-sample generators (seed = global sample index), batches dealt
-    round-robin, one all-gather, rank 0 gets every batch for saving, in order (src/experiments.py:923-961)."""
+def test_evaluate_edm_two_ranks_equal_single_process(tmp_path):
+    """EDMImageExperiment.evaluate_edm under WORLD_SIZE=2: per-sample generators (seed = global sample index), to-do batches
+    dealt round-robin, one all-gather, rank 0 writes every file under the single-process names; a batch whose files exist is
+    skipped by both (src/experiments.py:923-961)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         os.environ.pop(k, None)
-    _edm_worker(0, 1, 0, q)
-    single, order1 = q.get(timeout=60)
+    one, two = tmp_path / "one", tmp_path / "two"
+    for d in (one, two):
+        d.mkdir()
+        for j in range(2):                                          # batch 3 of 5 is already there
+            torch.save(torch.full((3, 4, 4), -7.0), d / f"00-00003-{j:03}.png")
+    _edm_worker(0, 1, 0, q, str(one))
+    single = q.get(timeout=60)
     port = _free_port()
-    procs = [ctx.Process(target=_edm_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_edm_worker, args=(r, 2, port, q, str(two))) for r in range(2)]
     for p in procs:
         p.start()
-    both, order2 = q.get(timeout=180)
+    both = q.get(timeout=180)
     for p in procs:
         p.join(timeout=180)
         assert p.exitcode == 0
-    assert order1 == order2 == list(range(5))
-    assert both.shape == (10, 3, 4, 4) and (both == single).all()
+    assert both.shape == (8, 3, 4, 4) and (both == single).all()                        # 4 sampled batches, in batch order
+    names = sorted(p.name for p in one.iterdir())
+    assert names == sorted(p.name for p in two.iterdir()) and len(names) == 10
+    for n in names:
+        assert torch.equal(torch.load(one / n), torch.load(two / n)), n
+    assert float(torch.load(two / "00-00003-001.png").mean()) == -7.0
+    # sample j of batch i was drawn from the generator seeded with its GLOBAL index: batch 4 = seeds 8, 9
+    g = torch.Generator().manual_seed(9)
+    want = (torch.randn((3, 4, 4), generator=g, dtype=torch.float64) * 0.4).add(1).div(2).clamp(0, 1)
+    assert torch.equal(torch.load(two / "00-00004-001.png"), want)
 
 
 # ---- the exchange half of the sigma-net training (SURVEY.md §8 f-4): DDP's construction-time parameter broadcast and its bucketed
