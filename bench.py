@@ -114,9 +114,17 @@ class AdmWorkload:
                          f"{args.dtype}, dynamic-threshold clip, learned variance, filler weights")
         self.gflop_per_image = self.timesteps * GF_PER_IMAGE_STEP if self.res == 256 else None
 
-    def inputs(self, n_total, world, rank):
+    @staticmethod
+    def host_noise_spec(args):
+        """(batch shape, seed) of the host draws, known before the models exist: main() replays the reference's generator on a
+        thread while the networks are built and packed."""
+        res = 64 if args.tiny else 256
+        return (args.batch or 16, 3, res, res), 1234
+
+    def inputs(self, n_total, world, rank, zs=None):
         from diffusion_nlc_amd import shard
-        zs = shard.draw_initial_noise(self.shape, n_total, 1234, world, rank)          # host, reference draw order
+        if zs is None:
+            zs = shard.draw_initial_noise(self.shape, n_total, 1234, world, rank)      # host, reference draw order
         if self.exp is None:
             return [z.to(self.device) for z in zs]
         sigma0 = self.exp.scheduler.sampling_sigmas[0]
@@ -240,7 +248,9 @@ class EdmWorkload:
                          f"({2 * self.steps - 1} evaluations), f64 state, batch {self.batch} per GPU, {args.dtype}, filler weights")
         self.gflop_per_image = (2 * self.steps - 1) * GF_EDM_EVAL
 
-    def inputs(self, n_total, world, rank):
+    host_noise_spec = None                      # per-sample generators: each rank draws only its own samples
+
+    def inputs(self, n_total, world, rank, zs=None):
         from diffusion_nlc_amd import shard
         from diffusion_nlc_amd.experiments import StackedRandomGenerator
         out = []
@@ -323,9 +333,14 @@ class CelebaWorkload:
                          f"DDIM+NLC, batch {self.batch} per GPU, {args.dtype}, clamp clip, fixedsmall variance, filler weights")
         self.gflop_per_image = self.timesteps * GF_CELEBA_STEP
 
-    def inputs(self, n_total, world, rank):
+    @staticmethod
+    def host_noise_spec(args):
+        return (args.batch or 8, 3, 256, 256), 5
+
+    def inputs(self, n_total, world, rank, zs=None):
         from diffusion_nlc_amd import shard
-        zs = shard.draw_initial_noise(self.shape, n_total, 5, world, rank)
+        if zs is None:
+            zs = shard.draw_initial_noise(self.shape, n_total, 5, world, rank)
         if self.exp is None:
             return [z.to(self.device) for z in zs]
         sigma0 = self.exp.scheduler.sampling_sigmas[0]
@@ -447,11 +462,26 @@ def main():
         torch.cuda.set_device(device)
     prec = PRECISIONS[args.dtype]
     dtype = prec[0]
+    n_total = (args.warmup + args.steps) * world
+    # Every rank replays the reference's single host generator over ALL global batches and keeps its own (shard.py): at
+    # --gpus 8 --steps 20 that is 168 draws of 12.6 MB per rank.  Off the critical path: a thread draws while the networks
+    # are built, filled and packed (torch.randn releases the GIL).
+    spec = WORKLOADS[args.config].host_noise_spec
+    noise_box, noise_thread, t_setup = {}, None, time.perf_counter()
+    if spec is not None:
+        import threading
+        nshape, nseed = spec(args)
+        noise_thread = threading.Thread(target=lambda: noise_box.update(zs=shard.draw_initial_noise(nshape, n_total, nseed, world, rank)))
+        noise_thread.start()
     wl = WORKLOADS[args.config](args, device, prec)
+    t_models = time.perf_counter() - t_setup
     if args.graph and wl.exp is not None:
         wl.exp.use_graphs = True
-    n_total = (args.warmup + args.steps) * world
-    xs = wl.inputs(n_total, world, rank)                                   # resident on the device before timing
+    if noise_thread is not None:
+        noise_thread.join()
+        assert tuple(noise_box["zs"][0].shape) == tuple(wl.shape)
+    xs = wl.inputs(n_total, world, rank, noise_box.get("zs"))               # resident on the device before timing
+    t_setup = time.perf_counter() - t_setup
 
     def one(x):
         return x * 0.5 if args.dry_run else wl.run(x)
@@ -470,13 +500,25 @@ def main():
     t0 = time.perf_counter()
     outs = [one(xs[args.warmup + i]) for i in range(args.steps)]           # finished samples stay on the device
     local_out = torch.stack(outs)
+    if use_gpu and world > 1:
+        torch.cuda.synchronize()            # phase stamp only (the collective below would wait for these kernels anyway)
+    t1 = time.perf_counter()
     gathered = shard.gather_samples(local_out, args.steps * world, world, rank)     # the one all-gather (RCCL over xGMI)
+    if use_gpu and world > 1:
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    # [whole region, sampling, all-gather (includes waiting for the slowest rank to arrive), final barrier, setup, models]
+    phases = torch.tensor([elapsed, t1 - t0, t2 - t1, t0 + elapsed - t2, t_setup, t_models], device=device, dtype=torch.float64)
+    t = phases[:1].clone()
+    per_rank = phases.view(1, -1)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        per_rank = phases.new_empty((world, phases.numel()))
+        torch.distributed.all_gather_into_tensor(per_rank.view(-1), phases)
     elapsed = float(t.item())
+    per_rank = per_rank.cpu()
     assert gathered.shape[0] == args.steps * world and torch.isfinite(gathered).all()
 
     images = wl.batch * args.steps * world
@@ -490,11 +532,16 @@ def main():
     }
     if args.graph:
         line["config"]["hipgraph"] = True
+    # what the first multi-GPU run needs to be diagnosable: the world size the process group really has, and where every rank's
+    # time went (a slow rank shows up as the OTHER ranks' gather time)
+    line["ranks_seen"] = torch.distributed.get_world_size() if (world > 1 and torch.distributed.is_initialized()) else 1
+    line["per_rank_seconds"] = {k: [round(float(v), 4) for v in per_rank[:, i]] for i, k in
+                                enumerate(["timed_region", "sampling", "all_gather", "final_barrier", "setup_untimed", "model_build_untimed"])}
     if rank == 0:
         if not args.dry_run and wl.gflop_per_image:
             line["end_to_end_tflops_per_gpu"] = (images / world) * wl.gflop_per_image / 1e3 / elapsed
         if not args.dry_run and not args.no_roofline:
-            line["roofline"] = roofline_leg(wl, xs[0], dtype, args)
+            line["roofline"] = roofline_leg(wl, xs[0], dtype, args, line["ms_per_step"])
         if not args.dry_run and not args.no_cpu_baseline and not args.tiny and world == 1:
             line["cpu_baseline"] = wl.cpu_baseline()
             if hasattr(wl, "parity"):
@@ -507,7 +554,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def roofline_leg(wl, x, dtype, args):
+def roofline_leg(wl, x, dtype, args, ms_per_step):
     """One more step of the same workload (outside the timed region, rank 0 only, no collective) with HIP events on the
     launch stream around every nlc_conv2d launch."""
     from diffusion_nlc_amd import ops
@@ -532,7 +579,19 @@ def roofline_leg(wl, x, dtype, args):
            "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3, >= 64 tiles) + conv_fast_kernel<{args.dtype},9|1> + conv_igemm_kernel",
            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
            "avg_launch_us": 1e3 * tot_ms / max(n, 1), "avg_launch_gflop": tot_fl / max(n, 1) / 1e9,
-           "share_of_step": tot_ms * 1e-3 / wall, "measured": "HIP events around every conv launch of one extra (untimed) step"}
+           # conv time of the instrumented step over the TIMED region's ms_per_step (reproducible from this line:
+           # launches x avg_launch_us / ms_per_step); the instrumented step itself ran `instrumented_step_ms`
+           "share_of_step": tot_ms / ms_per_step, "instrumented_step_ms": 1e3 * wall, "dominant_frac": None,
+           "measured": "HIP events around every conv launch of one extra (untimed) step"}
+    dom = []
+    if wl.name == "adm256" and wl.res == 256:
+        # the dominant launch's OWN fraction of peak (conv3x3 256->256 @256x256: the largest single share of the step)
+        dom = [(m, f) for m, f, shp in sel if shp[:4] == (wl.batch * 256 * 256, 256, 9, 256) and shp[5] == 0]
+    if dom:
+        out["dominant_frac"] = sum(f for _, f in dom) / sum(m for m, _ in dom) / 1e9 / peak
+        out["dominant_launch"] = {"shape": "conv3x3 256->256 @256x256, B=%d" % wl.batch, "launches": len(dom),
+                                  "launch_us": 1e3 * sum(m for m, _ in dom) / len(dom),
+                                  "tflops": sum(f for _, f in dom) / sum(m for m, _ in dom) / 1e9}
     # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
     # tagged with the hash of the kernel sources they were taken on
     tfiles = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))          # the newest round's profile
@@ -542,7 +601,6 @@ def roofline_leg(wl, x, dtype, args):
         out["traffic"] = tj.get("conv2d_bytes_per_launch")
         out["traffic_source"] = {"file": f"profiles/{tpath.name}", "csrc_sha16": tj.get("csrc_sha16"),
                                  "matches_this_build": tj.get("csrc_sha16") == csrc_sha16()}
-        dom = [(m, f) for m, f, shp in sel if shp[:4] == (wl.batch * 256 * 256, 256, 9, 256) and shp[5] == 0]
         if dom and "dominant" in tj:
             out["traffic_of_dominant_launch"] = {"kernel": tj["dominant"]["kernel"], "traffic": tj["dominant"]["traffic_bytes_per_launch"],
                                                  "algorithmic_bytes": tj["dominant"]["algorithmic_bytes_per_launch"],

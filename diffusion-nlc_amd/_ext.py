@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NLC_HIP_LIB", _HERE / "libnlc_hip.so"))     # override: kernel A/B experiments only
 BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
 
-ABI_VERSION = 4                 # NLC_ABI_VERSION of include/nlc_hip.h
+ABI_VERSION = 5                 # NLC_ABI_VERSION of include/nlc_hip.h
 NLC_F32, NLC_BF16, NLC_F16 = 0, 1, 2
 MATH_NATIVE, MATH_F16X3 = 0, 1      # nlc_conv_desc.math / nlc_pack_conv_weights_ex
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -29,7 +29,15 @@ VAR_MODES = {"none": 0, "fixedsmall": 1, "fixedlarge": 2, "learned": 3}
 
 
 class NlcError(RuntimeError):
-    pass
+    """Raised for every failure of the HIP path.  ``rc`` is the library's return code when one is known (NLC_EINVAL -1: the
+    call was rejected before anything was launched; NLC_ELAUNCH -2: a launch failed; NLC_EUNSUPPORTED -3)."""
+
+    def __init__(self, msg="", rc=None):
+        super().__init__(msg)
+        self.rc = rc
+
+
+NLC_EINVAL, NLC_ELAUNCH, NLC_EUNSUPPORTED = -1, -2, -3
 
 
 class ConvDesc(C.Structure):
@@ -63,6 +71,7 @@ class ConvDesc(C.Structure):
         ("stats_granule", C.c_int32),
         ("math", C.c_int32),
         ("debug", C.c_int32),
+        ("w_scale", C.c_void_p),
     ]
 
 
@@ -100,8 +109,7 @@ SIGNATURES = {
     "nlc_last_error": (C.c_char_p, []),
     "nlc_conv_pack_dims": (C.c_int, [_i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nlc_pack_conv_weights": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    "nlc_pack_conv_weights_ex": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "nlc_has_experiments": (C.c_int, []),
+    "nlc_pack_conv_weights_ex": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "nlc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _i, _vp]),
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
@@ -143,13 +151,12 @@ SIGNATURES = {
 _lib = None
 
 
-def build(force: bool = False, experiments: bool = False) -> Path:
-    """Compile the HIP sources for gfx950 (works without a GPU).  ``experiments``: also csrc/experiments/ (conv_wide,
-    conv_tall - never reached by the production dispatch, not part of the shipped library)."""
+def build(force: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 (works without a GPU)."""
     if force:
         for o in (_HERE / "csrc" / "obj").glob("*.o"):
             o.unlink()
-    subprocess.run(["bash", str(BUILD_SCRIPT)] + (["--experiments"] if experiments else []), check=True)
+    subprocess.run(["bash", str(BUILD_SCRIPT)], check=True)
     return LIB_PATH
 
 
@@ -181,7 +188,7 @@ def load() -> C.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().nlc_last_error().decode("utf-8", "replace")
-        raise NlcError(f"{what} failed (rc={rc}): {msg}")
+        raise NlcError(f"{what} failed (rc={rc}): {msg}", rc=rc)
 
 
 def pack_dims(dtype: int):

@@ -249,9 +249,9 @@ constexpr int F_SUB = 1;                               // 64-key tiles per stage
 constexpr int F_TILE = FKV * 128;                      // one K or V tile: 64 rows x 128 B
 constexpr int F_STAGE = F_SUB * F_TILE;
 // Workgroup shape W (waves = 32-query blocks per workgroup; the K / V tiles are shared by them) and K / V stages NST (NST - 1 tiles
-// in flight while one computes) are template parameters: (8, 2) ships; (8, 4), (4, 2), (4, 4) and a software-pipelined form
-// (experiments/attention_pipelined.inc) exist only in the diagnostic build -DNLC_ATTN_VARIANTS and were measured against it
-// (profiles/r03_summary.md: all within +-4 % or slower - neither DMA depth nor barrier lockstep nor the VALU count bounds it).
+// in flight while one computes) are template parameters: (8, 2) ships; (8, 4), (4, 2), (4, 4) and a software-pipelined form were
+// measured against it in round 3 (profiles/r03_summary.md §6: all within +-4 % or slower - neither DMA depth nor barrier lockstep
+// nor the VALU count bounds it; the diagnostic dispatch and the pipelined kernel are in the history, commit 489a09b).
 
 
 __device__ __forceinline__ int fk_swz(int row) { return (row >> 1) & 7; }                              // ds_read_b128 of K rows
@@ -487,10 +487,6 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
 }
 
 
-#ifdef NLC_ATTN_VARIANTS
-#include "experiments/attention_pipelined.inc"
-#endif
-
 template <typename T, bool BASE2, int W, int NST>
 int launch_d64v(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
     constexpr int LDS = 2 * NST * F_STAGE;
@@ -505,15 +501,6 @@ int launch_d64v(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st
 
 template <typename T, bool BASE2>
 int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
-#ifdef NLC_ATTN_VARIANTS                                  /* diagnostic build (tools/variant.sh attention "-DNLC_ATTN_VARIANTS"): A/B of the shapes */
-    static const char* v = getenv("NLC_ATTN_VARIANT");
-    if (v && v[0] == 'a') return launch_d64v<T, BASE2, 8, 2>(qkv, out, B, Tn, H, st);
-    if (v && v[0] == 'b') return launch_d64v<T, BASE2, 8, 4>(qkv, out, B, Tn, H, st);
-    if (v && v[0] == 'c') return launch_d64v<T, BASE2, 4, 2>(qkv, out, B, Tn, H, st);
-    if (v && v[0] == 'd') return launch_d64v<T, BASE2, 4, 4>(qkv, out, B, Tn, H, st);
-    if (v && v[0] == 'p') return launch_d64p<T, BASE2, 8>(qkv, out, B, Tn, H, st);      // experiments/attention_pipelined.inc
-    if (v && v[0] == 'q') return launch_d64p<T, BASE2, 4>(qkv, out, B, Tn, H, st);
-#endif
     return launch_d64v<T, BASE2, ATTN_W, ATTN_NST>(qkv, out, B, Tn, H, st);
 }
 

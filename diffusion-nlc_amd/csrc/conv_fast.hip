@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     const int mt = bid / p.NT, nt = bid - mt * p.NT;
     const int m0 = mt * BM, n0 = nt * BN;
 
+    if constexpr (X3 && std::is_same<T, float>::value) f16x3_enter();   // f32 -> f16 conversions saturate (conv_params.h)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lr = tid >> 3;                            // LDS row (mod 32) this lane's DMA lands in
@@ -482,6 +483,11 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
             done = true;
         }
     }
+    float wsc[16];                                   // X3: power-of-two factor of each output channel's sum (exact); n + 15 < Cout_pad
+    if constexpr (X3 && std::is_same<T, float>::value) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wsc[k] = p.w_scale[n + k];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (done) break;
@@ -492,7 +498,10 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg] + cbias[j * 4 + reg];
+            for (int reg = 0; reg < 4; ++reg) {
+                if constexpr (X3 && std::is_same<T, float>::value) v[j * 4 + reg] = acc[i][j][reg] * wsc[j * 4 + reg] + cbias[j * 4 + reg];
+                else v[j * 4 + reg] = acc[i][j][reg] + cbias[j * 4 + reg];
+            }
         if (p.emb) {
             const float* ep = p.emb + (int64_t)b * p.emb_stride;
             float ev[16];

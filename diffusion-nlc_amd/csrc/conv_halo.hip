@@ -144,6 +144,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     constexpr bool has_x3 = X3 && std::is_same<T, float>::value;
     constexpr bool has_xf = has_gn || has_x3;        // landed halo rows are transformed in LDS by the wave that fetched them
     static_assert(!(has_gn && has_x3), "GroupNorm prologue and split-f16 math are separate instantiations");
+    if constexpr (has_x3) f16x3_enter();             // f32 -> f16 conversions saturate instead of overflowing to inf (conv_params.h)
     const bool coef_wave = has_gn && wave == 1;      // wave-uniform
     const int ncb = p.Cin_pad / KBE;
     const int nk = ncb * 9;
@@ -640,6 +641,17 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 inited = true;
             }
         }
+        if constexpr (has_x3) {
+            // the packed weights of output row n carry the factor 2^e[n] (nlc_pack_conv_weights_ex): the sums are multiplied by
+            // w_scale[n] = 2^-e[n] in place - a power of two, exact - before anything is added (n + 15 < Cout_pad: in range)
+            const float4* wp4 = reinterpret_cast<const float4*>(p.w_scale + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 wq = wp4[q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc[i][q][0] *= wq.x; acc[i][q][1] *= wq.y; acc[i][q][2] *= wq.z; acc[i][q][3] *= wq.w; }
+            }
+        }
         if constexpr (!FOLD) {
             // f32 tensors (exact-f32 and split-f16 math), whole N-tile, NHWC, no activation, 16-byte-aligned bias / embedding: vector
             // loads of the bias and embedding slices and of all sixteen residual chunks up front, the reference's order of additions
@@ -996,7 +1008,7 @@ static bool halo_eligible(const KParams& p, int dtype, bool* forced_out) {
     // benchmark measures are chosen by the caller, launch by launch
     const bool forced = p.policy == NLC_CONV_FORCE_HALO;
     if (forced_out) *forced_out = forced;
-    if (p.policy == NLC_CONV_NO_HALO || p.policy == NLC_CONV_GENERIC) return false;       // (FORCE_WIDE: production rules for the rest)
+    if (p.policy == NLC_CONV_NO_HALO || p.policy == NLC_CONV_GENERIC) return false;
     if (!(p.KH == 3 && p.KW == 3 && p.pad_t == 1 && p.pad_l == 1 && p.stride == 1)) return false;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     if (p.Hout % PATCH || p.Wout % PATCH || p.Hout != HL || p.Wout != WL) return false;
@@ -1034,7 +1046,6 @@ static bool halo_plain_ok(const KParams& p, int dtype) {
 int nlc_conv_halo_plain_ok(const KParams& p, int dtype) { return halo_plain_ok(p, dtype) ? 1 : 0; }
 
 int nlc_conv_halo_prologue_ok(const KParams& p, int dtype) {
-    if (p.tuning & 16) return 0;                     // A/B runs: GroupNorm prologue in conv_tall only (tuning bit 4)
     return dtype == NLC_BF16 && halo_plain_ok(p, dtype) ? 1 : 0;
 }
 

@@ -21,6 +21,7 @@
 //         with the same k permutation on both operands.
 #include "common.h"
 #include "conv_params.h"
+#include <cstring>
 #include <stdlib.h>
 
 namespace {
@@ -137,6 +138,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // X3: the packed weights of output row n carry the factor 2^e[n] (nlc_pack_conv_weights_ex); multiplying the rebuilt weight by
+    // w_scale[n] = 2^-e[n] is exact, so this kernel's sum is the unscaled one
+    float wsj[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (X3 && std::is_same<T, float>::value) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wsj[j] = p.w_scale[n0 + wn * 64 + j * 16 + fr];          // < Cout_pad: in range
+    }
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE_BYTES;
         const char* Bs = As + BM * KB_BYTES;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_igemm_kernel(const KParams p
                 const f16x8_t wl = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(Bs + lds_off(wn * 64 + j * 16 + fr, 4 + fq)));
                 float wv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) wv[e] = (float)wh[e] + (float)wl[e];
+                for (int e = 0; e < 8; ++e) wv[e] = ((float)wh[e] + (float)wl[e]) * wsj[j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float av[8] = {__uint_as_float(fa0[i].x), __uint_as_float(fa0[i].y), __uint_as_float(fa0[i].z), __uint_as_float(fa0[i].w),
@@ -243,18 +251,6 @@ extern "C" int nlc_conv_pack_dims(int dtype, int* cout_mult, int* cin_mult) {
     return NLC_OK;
 }
 
-#ifndef NLC_EXPERIMENTS
-// the shipped library has no conv_wide / conv_tall (csrc/experiments/, `build.sh --experiments`): inert stand-ins
-int nlc_conv_wide_stats_partials(const KParams&, int) { return 0; }
-int nlc_conv_wide_dispatch(const KParams&, int, hipStream_t) { return NLC_EUNSUPPORTED; }
-int nlc_conv_tall_stats_partials(const KParams&, int) { return 0; }
-int nlc_conv_tall_dispatch(const KParams&, int, hipStream_t) { return NLC_EUNSUPPORTED; }
-int nlc_conv_tall_prologue_ok(const KParams&, int) { return 0; }
-extern "C" int nlc_has_experiments(void) { return 0; }
-#else
-extern "C" int nlc_has_experiments(void) { return 1; }
-#endif
-
 // ONE function fills the kernel parameter block from the descriptor, for the three host queries and for nlc_conv2d alike, so that
 // a query predicts the dispatch from exactly the state the launch sees (Cout_pad, residual, math mode, ... included).
 static void fill_params(const nlc_conv_desc* d, KParams& p) {
@@ -271,7 +267,7 @@ static void fill_params(const nlc_conv_desc* d, KParams& p) {
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
     p.ksplit = 1; p.partial = nullptr;
     p.stats = nullptr; p.stats_P = 0;
-    p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math;
+    p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math; p.w_scale = d->w_scale;
     p.policy = d->policy; p.tuning = d->tuning;
     p.stats_gran = d->stats_granule == 4 ? 4 : 8;
     p.div_hwo = FastDiv::make(d->Hout * d->Wout); p.div_wo = FastDiv::make(d->Wout);
@@ -287,8 +283,7 @@ extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype)
     fill_params(d, p);
     if (nlc_conv_narrow_ok(p, dtype)) return 0;
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
-    int ks = 1;
-    if (nlc_conv_tall_stats_partials(p, dtype) == 0 && nlc_conv_wide_stats_partials(p, dtype) == 0) ks = nlc_conv_halo_ksplit(p, dtype);
+    const int ks = nlc_conv_halo_ksplit(p, dtype);
     if (ks > 1) return (int64_t)ks * M64 * d->Cout * (int64_t)sizeof(float) + 4096;      // arrival counters in front of the halo kernel's partial sums
     if (nlc_conv_halo_plain_ok(p, dtype)) return 0;
     return nlc_conv_fast_split_bytes(p, nlc_conv_fast_ksplit(p, dtype));
@@ -299,11 +294,7 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     KParams p{};
     fill_params(d, p);
     if (nlc_conv_narrow_ok(p, dtype)) return 0;          // the <= 16-channel kernel emits none
-    int P = nlc_conv_tall_stats_partials(p, dtype);
-    if (P > 0) return P;
-    P = nlc_conv_wide_stats_partials(p, dtype);
-    if (P > 0) return P;
-    P = nlc_conv_halo_stats_partials(p, dtype);
+    const int P = nlc_conv_halo_stats_partials(p, dtype);
     if (P > 0) return P;
     return nlc_conv_fast_stats_partials(p, dtype);
 }
@@ -314,7 +305,40 @@ extern "C" int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype) 
     fill_params(d, p);
     p.gn_coef = nullptr;                                 // "the gn_* fields themselves are not looked at"
     if (nlc_conv_narrow_ok(p, dtype)) return 0;
-    return nlc_conv_tall_prologue_ok(p, dtype) || nlc_conv_halo_prologue_ok(p, dtype);
+    return nlc_conv_halo_prologue_ok(p, dtype);
+}
+
+// nlc_conv_desc.debug bit 1 (NLC_MATH_F16X3): the operand split needs |x| < 65504 (include/nlc_hip.h).  max |x| over the input
+// tensor(s) as an atomicMax on the f32 bit patterns (monotonic for non-negative values; a NaN's pattern is above infinity's), read
+// back through a device-global word.  Synchronises the stream: tests and triage only.
+__device__ unsigned g_x3_absmax_bits;
+__global__ __launch_bounds__(256) void x3_absmax_kernel(const float* __restrict__ x, int64_t n) {
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(fabsf(x[i])));
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&g_x3_absmax_bits, m);
+}
+static int check_x3_domain(const nlc_conv_desc* d, hipStream_t stream) {
+    unsigned bits = 0;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_x3_absmax_bits), &bits, sizeof(bits), 0, hipMemcpyHostToDevice, stream) != hipSuccess) {
+        nlc_set_error("nlc_conv2d: debug bit 1: could not reset the domain-check word");
+        return NLC_ELAUNCH;
+    }
+    const int64_t pix = (int64_t)d->B * d->Hin * d->Win;
+    const int64_t n0 = pix * d->C0, n1 = pix * d->C1;
+    hipLaunchKernelGGL(x3_absmax_kernel, dim3((unsigned)(cdiv(n0, 256) < 1024 ? cdiv(n0, 256) : 1024)), dim3(256), 0, stream, (const float*)d->x0, n0);
+    if (d->x1) hipLaunchKernelGGL(x3_absmax_kernel, dim3((unsigned)(cdiv(n1, 256) < 1024 ? cdiv(n1, 256) : 1024)), dim3(256), 0, stream, (const float*)d->x1, n1);
+    NLC_CHECK_LAUNCH("nlc_conv2d(debug: F16X3 domain check)");
+    if (hipMemcpyFromSymbolAsync(&bits, HIP_SYMBOL(g_x3_absmax_bits), sizeof(bits), 0, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+        nlc_set_error("nlc_conv2d: debug bit 1: could not read back the domain-check word");
+        return NLC_ELAUNCH;
+    }
+    float mx;
+    memcpy(&mx, &bits, sizeof(mx));
+    NLC_REQUIRE(bits < 0x477fe000u /* 65504.0f */, "nlc_conv2d: NLC_MATH_F16X3 input has max |x| = %g (or a NaN): outside the domain |x| < 65504 of the f16 operand split", (double)mx);
+    return NLC_OK;
 }
 
 // nlc_conv_desc.debug bit 0: the split-K arrival counters (first 4 KiB of the workspace) must be zero when a launch starts - every
@@ -336,6 +360,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(d != nullptr, "nlc_conv2d: null descriptor");
     NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_conv2d: bad dtype %d", dtype);
     NLC_REQUIRE(d->math == NLC_MATH_NATIVE || (d->math == NLC_MATH_F16X3 && dtype == NLC_F32), "nlc_conv2d: math %d needs dtype NLC_F32", d->math);
+    NLC_REQUIRE((d->math == NLC_MATH_F16X3) == (d->w_scale != nullptr),
+                "nlc_conv2d: w_scale (from nlc_pack_conv_weights_ex) is required with NLC_MATH_F16X3 and must be NULL otherwise");
     const int per = nlc_is16(dtype) ? 8 : 4;
     const int kbe = nlc_is16(dtype) ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
     NLC_REQUIRE(d->x0 && d->w && d->out, "nlc_conv2d: null tensor pointer");
@@ -363,13 +389,10 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(M64 < (1ll << 31) - BM, "nlc_conv2d: too many output pixels");
     NLC_REQUIRE(!d->res_upsample2x || (d->res && d->Hout % 2 == 0 && d->Wout % 2 == 0), "nlc_conv2d: res_upsample2x needs a residual and even Hout, Wout");
     NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
-    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_TALL, "nlc_conv2d: bad policy %d", d->policy);
+    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: bad policy %d", d->policy);
     NLC_REQUIRE(d->stats_granule == 0 || d->stats_granule == 4 || d->stats_granule == 8, "nlc_conv2d: stats_granule must be 0 (= 8), 4 or 8");
-    if (d->policy > NLC_CONV_GENERIC && !nlc_has_experiments()) {
-        nlc_set_error("nlc_conv2d: policy %d selects an experimental kernel; this library was built without --experiments", d->policy);
-        return NLC_EUNSUPPORTED;
-    }
 
+    if ((d->debug & 2) && d->math == NLC_MATH_F16X3) { const int cr = check_x3_domain(d, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
     KParams p;
     fill_params(d, p);
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
@@ -378,23 +401,16 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     if (!force_generic) {
         int Pfast = 0;
         if (d->stats_out) {
-            const int Ptall = nlc_conv_tall_stats_partials(p, dtype);
-            const int Pwide = Ptall > 0 ? Ptall : nlc_conv_wide_stats_partials(p, dtype);
-            const int Phalo = Pwide > 0 ? Pwide : nlc_conv_halo_stats_partials(p, dtype);
+            const int Phalo = nlc_conv_halo_stats_partials(p, dtype);
             Pfast = Phalo > 0 ? 0 : nlc_conv_fast_stats_partials(p, dtype);
             const int P = nlc_conv_narrow_ok(p, dtype) ? 0 : (Phalo > 0 ? Phalo : Pfast);
             NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
             NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / p.stats_gran) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
-            NLC_REQUIRE(p.stats_gran == 8 || !nlc_has_experiments() || d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: the experimental kernels emit 8-channel statistics only");
             p.stats = (float*)d->stats_out; p.stats_P = P;
         }
-        NLC_REQUIRE(!p.gn_coef || nlc_conv_tall_prologue_ok(p, dtype) || nlc_conv_halo_prologue_ok(p, dtype),
+        NLC_REQUIRE(!p.gn_coef || nlc_conv_halo_prologue_ok(p, dtype),
                     "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue (ask nlc_conv2d_prologue_supported first)");
         int rc = nlc_conv_narrow_dispatch(p, dtype, (hipStream_t)stream);
-        if (rc != NLC_EUNSUPPORTED) return rc;
-        rc = nlc_conv_tall_dispatch(p, dtype, (hipStream_t)stream);
-        if (rc != NLC_EUNSUPPORTED) return rc;
-        rc = nlc_conv_wide_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         const int hks = nlc_conv_halo_ksplit(p, dtype);
         if (hks > 1 && d->workspace && d->workspace_bytes >= (int64_t)hks * p.M * p.Cout * (int64_t)sizeof(float) + 4096) {

@@ -49,6 +49,7 @@ struct KParams {
     const float* gn_coef; int gn_act;   // conv_halo (bf16) only: input = act(a x + b) applied in LDS (nlc_conv_desc.gn_coef)
     int res_ups;        // res is [B][Hout/2][Wout/2][Cout]: output pixel (y, x) adds res pixel (y >> 1, x >> 1) (nlc_conv_desc.res_upsample2x)
     int math;           // NLC_MATH_* (nlc_conv_desc.math): f32 tensors only; F16X3 = weights packed as (hi, lo) f16 halves
+    const float* w_scale; // F16X3: [Cout_pad] power-of-two factor of every output channel's conv sum (nlc_conv_desc.w_scale), else NULL
     int stats_gran;     // channels per chunk of `stats` (nlc_conv_desc.stats_granule): 8, or 4 for consumers whose groups are 4 channels wide
     FastDiv div_hwo, div_wo;    // by Hout * Wout and by Wout (output row index -> image, y, x)
 };
@@ -111,6 +112,11 @@ __device__ __forceinline__ void f16x3_split4(const uint4& x, uint2& hi, uint2& l
     hi = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
     lo = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
 }
+// The X3 kernels run with MODE.FP16_OVFL = 1 (hwreg(HW_REG_MODE, 23, 1)): an f32 -> f16 conversion that overflows gives +-65504
+// instead of +-inf, so an activation outside the mode's domain (|x| >= 65504, include/nlc_hip.h) saturates - hi = +-65504, lo = the
+// clamped remainder - and the convolution sum stays finite; true infinities / NaNs of the input still propagate.  One scalar
+// instruction at kernel entry; nothing else in those kernels converts to f16.
+__device__ __forceinline__ void f16x3_enter() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
 __device__ __forceinline__ void mfma_f16(const uint4& a, const uint4& b, f32x4_t& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
@@ -139,12 +145,6 @@ int nlc_conv_halo_plain_ok(const KParams& p, int dtype);          // the un-spli
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: partials per image the halo kernel would emit GroupNorm statistics with for this launch (0: it would not)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype);
-// experiments/conv_wide.hip (only in --experiments builds): the 512-pixel-tile variant of the halo kernel; same conventions as the two below
-int nlc_conv_wide_stats_partials(const KParams& p, int dtype);
-int nlc_conv_wide_dispatch(const KParams& p, int dtype, hipStream_t stream);
-int nlc_conv_tall_stats_partials(const KParams& p, int dtype);     // conv_tall.hip: 256-pixel x 256-channel tiles
-int nlc_conv_tall_dispatch(const KParams& p, int dtype, hipStream_t stream);
-int nlc_conv_tall_prologue_ok(const KParams& p, int dtype);
 // conv_narrow.hip: 3x3 with at most 16 output channels (the networks' last layer)
 int nlc_conv_narrow_ok(const KParams& p, int dtype);
 int nlc_conv_narrow_dispatch(const KParams& p, int dtype, hipStream_t stream);

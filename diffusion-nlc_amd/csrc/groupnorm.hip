@@ -187,13 +187,8 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const GNParams p) {
 }
 
 // ---- fast path: nslot == 1 ---------------------------------------------------------------------------------
-#ifndef GN_UNR
-#define GN_UNR 8
-#endif
-#ifndef GN_APPLY_MAXBLK
-#define GN_APPLY_MAXBLK 8192
-#endif
-constexpr int UNR = GN_UNR;          // tuning knobs of the diagnostic builds (tools/variant.sh)
+constexpr int UNR = 8;                       // 16-byte loads in flight per lane of the streaming kernels; 4 / 16 measured within 3 % (round 2)
+constexpr int GN_APPLY_MAXBLK = 8192;        // largest apply grid (1024 ... 8192 workgroups measured within 3 %)
 
 template <typename T>
 __global__ __launch_bounds__(NT) void gn_stats_fast_kernel(const GNParams p) {
@@ -577,9 +572,7 @@ static int finalize_tpg(int gs, int P0, int P1, int C0, int C1) {
 static int apply_pix_per_block(int HW, int B, int ps, int unit) {
     int ppb = unit;
     while ((int64_t)cdiv(HW, ppb) * B > GN_APPLY_MAXBLK) ppb *= 2;
-#ifndef GN_NO_SMALL_GRID                            // diagnostic build: the fixed unit, for A/B runs (tools/variant.sh)
     while (ppb > ps && (int64_t)cdiv(HW, ppb) * B < 512) ppb /= 2;
-#endif
     return ppb;
 }
 
@@ -668,9 +661,7 @@ extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, in
     const int tpg = finalize_tpg(p.gs, P0, P1, C0, C1);
     hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
                        eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, g1);
-#ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
     p.coef = coef;
-#endif
     NLC_SWITCH_16(dtype, hipLaunchKernelGGL(gn_apply_fast_kernel<T16>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb));
     NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
     return NLC_OK;
@@ -704,9 +695,7 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
         const int tpg = finalize_tpg(p.gs, P0, 0, C, 0);
         hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
                            groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, 8);
-    #ifndef GN_NO_COEF                                  /* diagnostic build (tools/variant.sh): per-thread coefficient algebra as before */
-    p.coef = coef;
-#endif
+        p.coef = coef;
     } else {
         const size_t lds_stats = (size_t)p.ps * p.C * 3 * sizeof(float);
         NLC_REQUIRE(lds_stats <= 64 * 1024, "nlc_groupnorm_pool2x2: LDS budget exceeded (C=%d)", C);

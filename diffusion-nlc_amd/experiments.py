@@ -263,6 +263,8 @@ class ExperimentDiffusion:
         stochastic = S.eta > 0 or S.variant in ("ddpm", "ddpm_orig")
         noise = None
         if stochastic:
+            if noise_list is None:
+                self.host_draws_used = getattr(self, "host_draws_used", 0) + 1
             noise = (noise_list[ind] if noise_list is not None else torch.randn(xt.shape)).to(dev, torch.float32).contiguous()
         x0 = torch.empty_like(xt)
         x_prev = torch.empty_like(xt)
@@ -328,14 +330,18 @@ class ExperimentDiffusion:
         ``randn(shape)`` per step, in step order.  ``return_on_device`` keeps the returned sample in HBM (the
         reference returns it on the CPU, :396; the sharded driver gathers it over RCCL first).  ``max_steps`` stops after
         that many timesteps of the schedule (parity checks against a partial oracle trajectory); with ``return_log`` the
-        NLC-corrected per-sample sigma_t of every timestep is kept in ``self.sigma_trace`` (a list of CPU [B] tensors)."""
+        NLC-corrected per-sample sigma_t of every timestep is kept in ``self.sigma_trace`` (a list of CPU [B] tensors) and the
+        state x_t every timestep STARTED from in ``self.xt_trace`` (CPU; teacher-forced per-timestep comparisons of two
+        precisions feed one run's x_t to the other's ``get_denoise_vector``)."""
         S = self.scheduler
         S.reset_state()
         dev = self.device
         sig_host = S.sampling_sigmas.detach().cpu()
         ts_host = S.timesteps.detach().cpu()
-        if xT is None:
+        self.host_draws_used = 0                 # randn(batch_shape) draws this call took from the host generator (sharded drivers
+        if xT is None:                           # pad an early NaN break up to host_draws_per_batch(): image_sample.py)
             xt, zt = self.get_noise_xt(shape=shape, gen=gen, norm_noise=norm_init_noise, sigma=sig_host[0])
+            self.host_draws_used = 1
         else:
             xt = xT.to(dev, torch.float32).contiguous()
             zt = self.convert_coordinate(xt, sigma=sig_host[0]) if return_log else None
@@ -357,10 +363,12 @@ class ExperimentDiffusion:
             flag_host = torch.zeros(2, dtype=torch.int32).pin_memory()
             flag_ev = [torch.cuda.Event(), torch.cuda.Event()]
             x0_before = x0
-        self.sigma_trace = []
+        self.sigma_trace, self.xt_trace = [], []
         for ind, (t, t_prev) in enumerate(pairwise(ts_host.tolist())):
             if max_steps is not None and ind >= max_steps:
                 break
+            if return_log:
+                self.xt_trace.append(xt.cpu())
             if ind == S.num_inference_steps - 1 and new_eta is not None:
                 S.eta = new_eta
             cur_style, cur_refine = style, bool(refine_prior_sigma)

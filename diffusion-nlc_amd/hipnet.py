@@ -94,8 +94,7 @@ class HipModule:
         #  static copy: the captured network must consume the same statistics an eager call would, not recompute them in another
         #  summation order)
         stats_of = lambda a: getattr(a, "_nlc_stats", None) if torch.is_tensor(a) else None
-        key = (fn.__name__, self.compute_dtype, self.matmul, ops.CONV_POLICY, ops.CONV_TUNING, ops.FUSE_GN_CONV, ops.FUSE_GN_POOL,
-               ops.FUSED_GN_STATS, len(args), tuple(sorted(kwargs)),
+        key = (fn.__name__, self.compute_dtype, self.matmul, ops.config_key(), len(args), tuple(sorted(kwargs)),
                tuple((tuple(a.shape), a.dtype, None if stats_of(a) is None else tuple(stats_of(a).shape)) if torch.is_tensor(a) else a
                      for a in items))
         cache = self.__dict__.setdefault("_graphs", {})
@@ -248,11 +247,15 @@ class HipModule:
                            "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
 
     def plan(self):
+        # the packed weights bake ops.ATTN_BASE2 in (log2(e) folded into the q rows): a flip re-packs
+        if self._plan is not None and self.__dict__.get("_plan_base2") != ops.ATTN_BASE2:
+            self._plan = None
         if self._plan is None:
             self._require_gpu()
             with torch.cuda.device(self.device):
                 spec = F32X3 if (self.compute_dtype == torch.float32 and self.matmul == "f16x3") else self.compute_dtype
                 self._plan = self._build(self._sd, self.device, spec)
+                self.__dict__["_plan_base2"] = ops.ATTN_BASE2
         return self._plan
 
     def _build(self, sd, device, dtype):

@@ -88,6 +88,7 @@ class PackedConv:
     Cout_pad: int
     dtype: torch.dtype
     math: int = MATH_NATIVE           # MATH_F16X3: f32 tensor holding (hi, lo) f16 halves - nlc_conv2d must be told (desc.math)
+    w_scale: Optional[torch.Tensor] = None   # MATH_F16X3: f32 [Cout_pad], the power-of-two factor per output row (desc.w_scale)
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype, device,
@@ -130,10 +131,13 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
         packed = torch.empty(Cout_pad, KH * KW, Cin_pad, device=device, dtype=dtype)
         has_bias = bd is not None or ba is not None
         bout = torch.empty(Cout, device=device, dtype=torch.float32) if has_bias else None
+        wsc = torch.empty(Cout_pad, device=device, dtype=torch.float32) if mcode == MATH_F16X3 else None
         check(lib.nlc_pack_conv_weights_ex(wd.data_ptr(), _ptr(bd), Cout, Cin, KH, KW, _ptr(rp), _ptr(rs), _ptr(ba), _ptr(cp),
-                                           dtype_enum(dtype), mcode, packed.data_ptr(), _ptr(bout), _stream()), "nlc_pack_conv_weights_ex")
+                                           dtype_enum(dtype), mcode, packed.data_ptr(), _ptr(bout), _ptr(wsc), _stream()),
+              "nlc_pack_conv_weights_ex")
         torch.cuda.current_stream().synchronize()      # load time: the f32 staging copies may be freed after this
-    return PackedConv(w=packed, bias=bout, Cin=Cin, Cout=Cout, KH=KH, KW=KW, Cin_pad=Cin_pad, Cout_pad=Cout_pad, dtype=dtype, math=mcode)
+    return PackedConv(w=packed, bias=bout, Cin=Cin, Cout=Cout, KH=KH, KW=KW, Cin_pad=Cin_pad, Cout_pad=Cout_pad, dtype=dtype, math=mcode,
+                      w_scale=wsc)
 
 
 # --------------------------------------------------------------------------------------
@@ -144,10 +148,11 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
 CONV_PROFILE = None
 # Kernel-selection policy handed to every nlc_conv2d call (nlc_conv_desc.policy): "auto" is the production dispatch;
 # tests and A/B tools pin a kernel with "halo" (LDS-halo kernel for every eligible shape), "no_halo" or "generic".
-CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3, "wide": 4, "tall": 5}
+CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3}
 CONV_POLICY = "auto"
 CONV_TUNING = 0              # nlc_conv_desc.tuning: schedule A/B switches for tools/ (0 in production)
-CONV_DEBUG = 0               # nlc_conv_desc.debug: bit 0 = verify the split-K arrival counters before every split launch (tests)
+CONV_DEBUG = 0               # nlc_conv_desc.debug: bit 0 = verify the split-K arrival counters before every split launch; bit 1 = verify
+                             # that f16x3 inputs are inside the split's domain |x| < 65504 (both synchronise: tests / triage)
 # Ride-along GroupNorm statistics come per 8 output channels - or per 4 when the consumer's groups are 4 / 12 / 20 ... channels wide:
 # with the networks' 32 groups that is every <= 128-channel tensor (cfg 4's two highest-resolution levels, EDM's first layer),
 # whose GroupNorm otherwise pays a statistics pass over HBM (0.74 ms per NLC step of cfg 4).  A/B switch.
@@ -228,7 +233,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
                  out_scale=out_scale, act=act, out=out.data_ptr(),
                  out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY], tuning=CONV_TUNING,
-                 res_upsample2x=1 if res_upsample2x else 0, math=pw.math, debug=CONV_DEBUG)
+                 res_upsample2x=1 if res_upsample2x else 0, math=pw.math, debug=CONV_DEBUG, w_scale=_ptr(pw.w_scale))
     if query_prologue:
         return bool(lib.nlc_conv2d_prologue_supported(C.byref(d), dtype_enum(dt)))
     if gn_coef is not None:
@@ -240,7 +245,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel
         P = lib.nlc_conv2d_stats_partials(C.byref(d), dtype_enum(dt))
         if P > 0:
-            gran = 8 if CONV_POLICY in ("wide", "tall") else stats_granule(pw.Cout)      # (the experimental kernels emit per 8 only)
+            gran = stats_granule(pw.Cout)
             stats = torch.empty(B, P, pw.Cout // gran, 2, device=x0.device, dtype=torch.float32)
             d.stats_out, d.stats_bytes, d.stats_granule = stats.data_ptr(), stats.numel() * 4, gran
     if is16(dt) or allow_split:      # split-K scratch for the few-tile / long-K levels (a cheap host query)
@@ -269,20 +274,33 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
 def _launch_conv(lib, d: ConvDesc, dt: torch.dtype) -> None:
     try:
         check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
-    except _ext.NlcError:
-        if d.workspace:
+    except _ext.NlcError as e:
+        if d.workspace and e.rc == _ext.NLC_ELAUNCH:
             # a split-K launch that did not complete may leave arrival counters non-zero, and every later split launch on this
-            # workspace would then reduce early or never: drop the workspace, the next call allocates a zeroed one
+            # workspace would then reduce early or never: drop the workspace, the next call allocates a zeroed one.  (A call the
+            # library REJECTED - NLC_EINVAL / NLC_EUNSUPPORTED - launched nothing and leaves the workspace as it was.)
             reset_conv_workspaces()
         raise
 
 
+WS_GENERATION = 0            # bumped by reset_conv_workspaces(): part of config_key(), so captured hipGraphs that reference a dropped
+                             # workspace are never replayed (HipModule re-captures under the new key)
+
+
 def reset_conv_workspaces() -> None:
-    """Forget every split-K workspace (they are re-allocated zeroed on demand).  Called after a failed nlc_conv2d.  The old buffers
-    stay allocated (captured hipGraphs may reference them) - a graph that replays a poisoned buffer must be re-captured
-    (HipModule.drop_graphs)."""
+    """Forget every split-K workspace (they are re-allocated zeroed on demand).  Called after a failed nlc_conv2d launch.  The old
+    buffers stay allocated - a hipGraph captured earlier may still hold their addresses - but no such graph is replayed again:
+    the generation counter is part of every graph's cache key."""
+    global WS_GENERATION
     _ws_retired.extend(_conv_ws.values())
     _conv_ws.clear()
+    WS_GENERATION += 1
+
+
+def config_key() -> tuple:
+    """Every module-level switch that changes which kernels / layouts a network evaluation launches.  HipModule keys its captured
+    hipGraphs by it (a graph bakes the configuration it was captured under); setters of these switches need no other hook."""
+    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_POOL, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2, WS_GENERATION)
 
 
 def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
@@ -311,19 +329,29 @@ def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
 
 _gn_ws = {}
 _conv_ws = {}
-_ws_retired = []             # outgrown workspaces stay allocated (hipGraphs captured earlier keep their addresses)
+_ws_retired = []             # outgrown workspaces stay allocated (hipGraphs captured earlier keep their addresses); bounded: _grown()
 FUSED_GN_STATS = True        # groupnorm() uses statistics emitted by the producing conv2d() when they are attached
 
 
+def _grown(nbytes: int) -> int:
+    """Workspace sizes grow geometrically (next power of two, at least 1 MiB): a sequence of growing requests retires at most
+    log2 buffers whose sizes sum to less than the live one - _ws_retired stays bounded."""
+    n = 1 << 20
+    while n < nbytes:
+        n <<= 1
+    return n
+
+
 def _conv_workspace(device, nbytes: int) -> torch.Tensor:
-    """Per (device, stream) scratch for nlc_conv2d's split-K partials; grows to the largest request.  Allocated ZEROED: its first
-    4 KiB are the library's arrival counters, which every launch leaves zero (include/nlc_hip.h, nlc_conv_desc.workspace)."""
+    """Per (device, stream) scratch for nlc_conv2d's split-K partials; grows geometrically to cover the largest request.  Allocated
+    ZEROED: its first 4 KiB are the library's arrival counters, which every launch leaves zero (include/nlc_hip.h,
+    nlc_conv_desc.workspace)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         if ws is not None:
             _ws_retired.append(ws)          # a captured hipGraph may still reference the smaller buffer: never hand it back
-        ws = torch.zeros(nbytes // 4 + 1, device=device, dtype=torch.float32)
+        ws = torch.zeros(_grown(nbytes) // 4, device=device, dtype=torch.float32)
         _conv_ws[key] = ws
     return ws
 
@@ -334,7 +362,7 @@ def _gn_workspace(device, nbytes: int) -> torch.Tensor:
     if ws is None or ws.numel() * 4 < nbytes:
         if ws is not None:
             _ws_retired.append(ws)
-        ws = torch.empty(max(nbytes // 4 + 1, 1 << 16), device=device, dtype=torch.float32)
+        ws = torch.empty(_grown(nbytes) // 4, device=device, dtype=torch.float32)
         _gn_ws[key] = ws
     return ws
 

@@ -223,7 +223,9 @@ def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=Fal
     batch takes from the generator (initial state + per-step noise of stochastic samplers), so each sample equals the
     single-process run's.  The skip-if-exists decisions (which do not advance the generator upstream either) are taken once, by
     rank 0, before anything is written.  One all-gather (RCCL over xGMI) collects the finished samples; rank 0 writes the PNGs
-    and computes FID.  ``return_log`` lists are per rank (rank 0 returns those of its own batches)."""
+    and computes FID.  ``return_log`` lists are per rank (rank 0 returns those of its own batches).  Cost to know about: with a
+    stochastic sampler (DDPM, eta > 0) every rank draws every batch's per-step noise on the host (world x the randn work per rank);
+    deterministic DDIM draws one tensor per batch."""
     from diffusion_nlc_amd import shard
     world, rank = shard.world_rank()
     B = experiment.batch_size
@@ -258,6 +260,11 @@ def evaluate_unconstraint(experiment, n_samples, images_dir, norm_init_noise=Fal
                                                           chunk_size=1, sigma_pred_threshold=sigma_pred_threshold, new_eta=new_eta,
                                                           **extra)
         print("time:", time() - t1)
+        if world > 1 and sampling != "project":
+            # a NaN early-break (src/experiments.py:389) leaves draws of a stochastic sampler untaken; the other ranks replayed the
+            # full count for this batch, so the owner pads up to it - the ranks stay in step with EACH OTHER (a single-process run,
+            # like the reference, carries on from wherever the break left the generator)
+            shard.replay_draws(gen, shape, experiment.host_draws_per_batch(new_eta) - getattr(experiment, "host_draws_used", experiment.host_draws_per_batch(new_eta)))
         logs.append(return_list)
         sample = sample.add(1).div(2).clamp(0, 1)
         if world == 1:

@@ -30,15 +30,26 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 4
+#define NLC_ABI_VERSION 5
 
 enum { NLC_F32 = 0, NLC_BF16 = 1, NLC_F16 = 2 };
 /* matrix arithmetic of nlc_conv2d on NLC_F32 tensors (nlc_conv_desc.math; weights must be packed for the same mode):
  *   NLC_MATH_NATIVE  the dtype's own MFMA (f32: exact v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit rate)
- *   NLC_MATH_F16X3   every f32 operand x is split into two halves, hi = f16(x), lo = f16(x - hi) (22 significand bits
- *                    between them), and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with f32 accumulate:
- *                    3/16 of the 16-bit rate instead of 1/16, relative error per product <= 2^-21.  Storage, bias, embedding,
- *                    residual, activation and every non-convolution kernel stay exact f32. */
+ *   NLC_MATH_F16X3   every f32 operand x is split into two halves, hi = f16(x), lo = f16(x - hi), and a product is
+ *                    hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with f32 accumulate: 3/16 of the 16-bit rate instead of
+ *                    1/16.  Storage, bias, embedding, residual, activation and every non-convolution kernel stay exact f32.
+ *                    Accuracy and domain (f16 has 11 significand bits, normal range 2^-14 .. 65504, subnormal spacing 2^-24):
+ *                      weights      are scaled per OUTPUT ROW by a power of two at pack time so that the row's largest |w| lies in
+ *                                   [2^14, 2^15) (nlc_pack_conv_weights_ex writes the inverse factors to w_scale_out, the
+ *                                   convolution multiplies its sum by nlc_conv_desc.w_scale[n] - exact): hi + lo carries 22
+ *                                   significand bits of every weight within 2^-17 of its row's maximum, and an absolute error
+ *                                   <= 2^-39 of that maximum below; no weight can overflow or lose its hi half.
+ *                      activations  are split unscaled, in the kernel: 22 significand bits for 2^-3 <= |x| < 65504, absolute
+ *                                   error <= 2^-25 below 2^-3 (lo is an f16 subnormal there) - the inputs of this path are
+ *                                   GroupNorm / SiLU outputs and residual streams of magnitude O(1..100).  |x| >= 65504 is
+ *                                   OUTSIDE the domain: the kernels run with the FP16_OVFL mode bit set, so such a value
+ *                                   saturates (hi = +-65504, lo = f16-clamped remainder: finite, never inf / NaN) instead of
+ *                                   poisoning the sum; nlc_conv_desc.debug bit 1 turns it into an error (NLC_EINVAL). */
 enum { NLC_MATH_NATIVE = 0, NLC_MATH_F16X3 = 1 };
 enum { NLC_OK = 0, NLC_EINVAL = -1, NLC_ELAUNCH = -2, NLC_EUNSUPPORTED = -3 };
 enum { NLC_ACT_NONE = 0, NLC_ACT_SILU = 1, NLC_ACT_GELU = 2 };
@@ -59,14 +70,9 @@ enum { NLC_VAR_NONE = 0, NLC_VAR_FIXEDSMALL = 1, NLC_VAR_FIXEDLARGE = 2, NLC_VAR
  * LDS-halo kernel for stride-1 3x3 "same" convolutions with >= 128 (16x16 pixel x 128 channel) tiles, else the LDS-DMA
  * implicit-GEMM kernel (3x3 / 1x1), else the generic gather kernel.  The others exist so that parity tests and A/B
  * timings can pin a kernel per call; there is no process-wide switch. */
-enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3, NLC_CONV_FORCE_WIDE = 4,
-       NLC_CONV_FORCE_TALL = 5 };
-/* (FORCE_WIDE / FORCE_TALL select two experimental tile shapes of the halo kernel, csrc/experiments/conv_{wide,tall}.hip.  They
- *  are NOT part of the shipped library: only a `csrc/build.sh --experiments` build contains them (nlc_has_experiments() == 1);
- *  without it nlc_conv2d rejects the two policies with NLC_EUNSUPPORTED.  AUTO never selects them.) */
+enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3 };
 
 int nlc_version(void);
-int nlc_has_experiments(void);   /* 1: built with --experiments (conv_wide / conv_tall present), 0: the shipped library */
 const char* nlc_last_error(void);
 
 /* Tile geometry the host needs to pack weights: Cout is padded to a multiple of
@@ -95,10 +101,14 @@ int nlc_pack_conv_weights(const float* w, const float* bias, int Cout, int Cin, 
 /* same with the matrix-arithmetic mode the weights will be used with (nlc_conv_desc.math).  math = NLC_MATH_F16X3 (dtype must
  * be NLC_F32): every 32-channel k-block (128 bytes) of a packed row holds, per 16-byte chunk c = 0..3, the f16 `hi` halves of
  * channels 4c..4c+3 and 16+4c..16+4c+3 (the 8 k-values one lane feeds to a 16x16x32 MFMA), and chunk 4+c the `lo` halves of the
- * same channels; hi = f16(x) rounded to nearest, lo = f16(x - hi). */
+ * same channels; hi = f16(x) rounded to nearest, lo = f16(x - hi), where x = 2^e[r] * (the value packed[r][tap][c] above) and
+ * 2^e[r] is the power of two that brings max |row r| into [2^14, 2^15) (e = 0 for an all-zero or padding row).
+ *   w_scale_out  f32 [Cout_pad], REQUIRED for NLC_MATH_F16X3 (ignored, may be NULL, otherwise): w_scale_out[r] = 2^-e[r];
+ *                hand it to nlc_conv2d as nlc_conv_desc.w_scale.  bias_out is NOT scaled. */
 int nlc_pack_conv_weights_ex(const float* w, const float* bias, int Cout, int Cin, int KH, int KW,
                              const int32_t* row_perm, const double* row_scale, const double* bias_add,
-                             const int32_t* col_perm, int dtype, int math, void* packed, float* bias_out, void* stream);
+                             const int32_t* col_perm, int dtype, int math, void* packed, float* bias_out, float* w_scale_out,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Convolution / linear as one implicit-GEMM MFMA kernel.
@@ -158,6 +168,11 @@ typedef struct nlc_conv_desc {
                          /* weight in the k order the kernels read, same byte size as the f32 packing.                                 */
     int32_t debug;       /* 0 in production.  Bit 0: before launching a split-K shape, copy the workspace's arrival counters back and   */
                          /* return NLC_EINVAL if any is non-zero (a poisoned workspace; synchronises the stream - tests / triage only). */
+                         /* Bit 1 (NLC_MATH_F16X3): reduce max |x| over the input tensor(s) first and return NLC_EINVAL if it is >= 65504 */
+                         /* or not finite - outside the domain of the operand split (synchronises the stream - tests / triage only).     */
+    const float* w_scale; /* NLC_MATH_F16X3: f32 [Cout_pad] from nlc_pack_conv_weights_ex (w_scale_out), REQUIRED in that mode: the     */
+                         /* conv sum of output channel n is multiplied by w_scale[n] (a power of two: exact) before bias / embedding /  */
+                         /* residual are added.  Must be NULL for NLC_MATH_NATIVE.                                                       */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);

@@ -35,11 +35,19 @@ class AdmConfig:
     feat_layer: int = 1
 
 
-def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
-    """src/nn_util.py:103-121: [cos(t f) || sin(t f)], f_i = exp(-ln(max_period) i / half)."""
+def _hi(x: torch.Tensor) -> torch.Tensor:
+    """The reference's ``.float()`` up-casts (GroupNorm32, softmax, timestep embedding) - except that a float64 tensor stays
+    float64: with a float64 state_dict and input the same graph evaluates in double precision end to end (the "f64 leg" of
+    tools/parity_trace.py: the function the f32 arithmetic approximates, same parameters)."""
+    return x if x.dtype == torch.float64 else x.float()
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0, dtype=torch.float32) -> torch.Tensor:
+    """src/nn_util.py:103-121: [cos(t f) || sin(t f)], f_i = exp(-ln(max_period) i / half).  The frequency table is computed in
+    f32 as upstream (it is a parameter of the function); ``dtype`` = float64 evaluates t f, cos and sin in double."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
-    args = t[:, None].float() * freqs[None]
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(dtype)
+    args = t[:, None].to(dtype) * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
         emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
@@ -48,7 +56,7 @@ def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -
 
 def _gn32(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     """GroupNorm32: 32 groups, eps 1e-5, computed in f32 (src/nn_util.py:17-19,93-100)."""
-    return F.group_norm(x.float(), 32, sd[p + ".weight"], sd[p + ".bias"], 1e-5).type(x.dtype)
+    return F.group_norm(_hi(x), 32, sd[p + ".weight"], sd[p + ".bias"], 1e-5).type(x.dtype)
 
 
 def _conv(sd: SD, p: str, x: torch.Tensor, stride: int = 1, padding: int = 1) -> torch.Tensor:
@@ -105,7 +113,7 @@ def attention_block(sd: SD, p: str, x: torch.Tensor, heads: int, new_order: bool
         q, k, v = qkv.reshape(bs * heads, ch * 3, length).split(ch, dim=1)
         q, k = q * scale, k * scale
     weight = torch.einsum("bct,bcs->bts", q, k)
-    weight = torch.softmax(weight.float(), dim=-1).type(weight.dtype)
+    weight = torch.softmax(_hi(weight), dim=-1).type(weight.dtype)
     a = torch.einsum("bts,bcs->bct", weight, v).reshape(bs, -1, length)
     h = F.conv1d(a, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
     return (x + h).reshape(b, c, *spatial)
@@ -137,7 +145,7 @@ def unet(sd: SD, cfg: AdmConfig, x: torch.Tensor, timesteps: torch.Tensor, mode:
     """
     ss = cfg.use_scale_shift_norm
     heads_up = cfg.num_heads if cfg.num_heads_upsample == -1 else cfg.num_heads_upsample
-    temb = timestep_embedding(timesteps, cfg.model_channels)
+    temb = timestep_embedding(timesteps, cfg.model_channels, dtype=sd["time_embed.0.weight"].dtype)
     emb = F.linear(temb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
     if y is not None:                                   # class-conditional: + label_emb(y) (src/unet_adm.py:652-654)

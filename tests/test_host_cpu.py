@@ -71,7 +71,6 @@ def test_argument_validation_without_gpu():
     assert lib.nlc_attention(None, None, 1, 1, 1, 64, 0, 0, None) == -1
     assert lib.nlc_conv_first(None, None, None, None, None, 1, 3, 8, 8, 16, 3, 3, 0, None, 0, 5, None) == -1        # stats_granule 5
     assert b"granule" in lib.nlc_last_error()
-    assert lib.nlc_has_experiments() == 0                            # the shipped library has no experimental kernels
     d2 = _ext.ConvDesc(math=1)
     assert lib.nlc_conv2d(ctypes.byref(d2), _ext.NLC_BF16, None) == -1 and b"math" in lib.nlc_last_error()        # F16X3 is a mode of f32 tensors
     assert lib.nlc_groupnorm(None, None, 8, 0, 1, 1, 3, 1e-5, None, None, None, None, 0, 0, None, None, 0, None) == -1

@@ -25,16 +25,6 @@ def _seed(obj) -> int:
     return zlib.crc32(repr(obj).encode()) & 0x7fffffff
 
 
-def _has_experiments() -> bool:
-    from diffusion_nlc_amd import _ext
-    return bool(_ext.load().nlc_has_experiments())
-
-
-def _need_experiments():
-    if not _has_experiments():
-        pytest.skip("conv_wide / conv_tall are only in a `csrc/build.sh --experiments` build (not the shipped library)")
-
-
 def _dev():
     return torch.device("cuda:0")
 
@@ -168,32 +158,113 @@ def test_conv2d_split_f16_math(case, conv_policy):
     _run_conv_case(case, torch.float32, "f16x3")
 
 
+X3_WEIGHTS = {
+    # magnitudes over 10 binades inside every row (exercises hi / lo of elements far below the row's maximum)
+    "binades": lambda g, shape: torch.randn(shape, generator=g) * torch.exp2(torch.randint(-10, 0, shape, generator=g).float()),
+    # what the networks carry: filler / trained weights of magnitude 1e-2 ... 1e-4.  UNSCALED, hi = f16(w) keeps 11 bits but lo falls
+    # into f16's subnormal range (absolute 2^-25): N(0, 0.02^2) carried ~19 bits, N(0, 1e-4^2) ~12.  The per-row power-of-two scale
+    # of nlc_pack_conv_weights_ex (row maximum -> [2^14, 2^15)) restores the full 22.
+    "n0.02": lambda g, shape: torch.randn(shape, generator=g) * 0.02,
+    "n1e-4": lambda g, shape: torch.randn(shape, generator=g) * 1e-4,
+    # rows of wildly different magnitude (per-ROW scaling, not per tensor), one all-zero row, one row with a single non-zero weight
+    "rows": lambda g, shape: _x3_rows(g, shape),
+}
+
+
+def _x3_rows(g, shape):
+    w = torch.randn(shape, generator=g) * torch.exp2(torch.randint(-30, 20, (shape[0], 1, 1, 1), generator=g).float())
+    w[3] = 0.0
+    w[5] = 0.0
+    w[5, 7, 1, 1] = 3.0e-7
+    return w
+
+
+@pytest.mark.parametrize("wkind", sorted(X3_WEIGHTS))
 @pytest.mark.parametrize("policy", ["auto", "halo", "no_halo", "generic"])
-def test_split_f16_math_carries_22_bits(policy):
-    """Adversarial operands for the operand split: magnitudes over 12 binades on both sides (the lo halves of the small ones are f16
+def test_split_f16_math_carries_22_bits(policy, wkind):
+    """Adversarial operands for the operand split: activation magnitudes over 12 binades (the lo halves of the small ones are f16
     subnormals), one input channel block where only lo halves are non-zero (values below half an f16 ulp of nothing: exact powers of
-    two times (1 + 2^-12)), against f64.  A kernel that dropped a cross term, flushed subnormal halves or mis-paired hi / lo lanes
-    fails this by orders of magnitude (bf16: 4e-3, plain f16: 5e-4, this mode: < 2e-6)."""
+    two times (1 + 2^-12)); weights of four kinds (X3_WEIGHTS), against f64, per OUTPUT ROW relative to that row's largest output
+    (a per-row scale must not let a large row hide a small one).  A kernel that dropped a cross term, flushed subnormal halves,
+    mis-paired hi / lo lanes or mis-applied the row scale fails this by orders of magnitude (bf16: 4e-3, plain f16: 5e-4,
+    this mode: < 2e-6)."""
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(123)
     B, Cin, H, W, Cout = 2, 64, 16, 16, 128
     mag = torch.exp2(torch.randint(-8, 4, (B, Cin, H, W), generator=g).float())
     x = torch.randn(B, Cin, H, W, generator=g) * mag
     x[:, 32:48] = (1 + 2.0 ** -12) * torch.exp2(torch.randint(-3, 3, (B, 16, H, W), generator=g).float())     # hi = 2^k, lo = 2^(k-12)
-    wmag = torch.exp2(torch.randint(-10, 0, (Cout, Cin, 3, 3), generator=g).float())
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * wmag
-    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    w = X3_WEIGHTS[wkind](g, (Cout, Cin, 3, 3))
+    bias = torch.randn(Cout, generator=g) * w.abs().amax(dim=(1, 2, 3))          # the bias must NOT be scaled with the row
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
     old = ops.CONV_POLICY
     ops.CONV_POLICY = policy
     try:
-        got = ops.conv2d(_nhwc(x, torch.float32), ops.pack_conv(w, None, torch.float32, _dev(), math="f16x3"))
-        exact = ops.conv2d(_nhwc(x, torch.float32), ops.pack_conv(w, None, torch.float32, _dev()))
+        pw = ops.pack_conv(w, bias, torch.float32, _dev(), math="f16x3")
+        got = ops.conv2d(_nhwc(x, torch.float32), pw)
+        exact = ops.conv2d(_nhwc(x, torch.float32), ops.pack_conv(w, bias, torch.float32, _dev()))
     finally:
         ops.CONV_POLICY = old
-    scale = ref.abs().max().item()
-    e3 = (got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() / scale
-    e1 = (exact.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() / scale
-    assert e3 < 2e-6, f"f16x3 under policy {policy}: {e3:.3e} (exact-f32 MFMA on the same data: {e1:.3e})"
+    # the row factors are powers of two that bring each row's maximum into [2^14, 2^15) (1 for an all-zero row)
+    ws = pw.w_scale.cpu()[:Cout].double()
+    assert torch.equal(torch.exp2(torch.round(torch.log2(ws))), ws)
+    wmax = w.abs().amax(dim=(1, 2, 3)).double()
+    nz = wmax > 0
+    scaled = wmax[nz] / ws[nz]
+    assert (scaled >= 2.0 ** 14).all() and (scaled < 2.0 ** 15).all() and (ws[~nz] == 1).all()
+    scale = ref.abs().amax(dim=(0, 2, 3)).clamp_min(1e-300)                      # per output channel
+    e3 = ((got.permute(0, 3, 1, 2).double().cpu() - ref).abs().amax(dim=(0, 2, 3)) / scale).max().item()
+    e1 = ((exact.permute(0, 3, 1, 2).double().cpu() - ref).abs().amax(dim=(0, 2, 3)) / scale).max().item()
+    assert e3 < 2e-6, f"f16x3 under policy {policy}, weights {wkind}: {e3:.3e} (exact-f32 MFMA on the same data: {e1:.3e})"
+
+
+@pytest.mark.parametrize("policy", ["auto", "halo", "no_halo", "generic"])
+def test_split_f16_math_domain_is_guarded(policy):
+    """|x| >= 65504 is outside the domain of the f16 operand split (include/nlc_hip.h).  In production such an input must not
+    poison the sum: the kernels run with FP16_OVFL set, so the value saturates and the output stays FINITE (round 3 produced
+    inf - inf = NaN); with nlc_conv_desc.debug bit 1 the launch is refused loudly instead.  Values just inside the domain are exact
+    to the mode's accuracy."""
+    from diffusion_nlc_amd import ops
+    from diffusion_nlc_amd._ext import NlcError
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, W, Cout = 1, 64, 16, 16, 128
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.02
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[0, 3, 5, 5] = 6.0e4                                       # inside
+    old, old_dbg = ops.CONV_POLICY, ops.CONV_DEBUG
+    ops.CONV_POLICY = policy
+    try:
+        pw = ops.pack_conv(w, None, torch.float32, _dev(), math="f16x3")
+        ops.CONV_DEBUG = 2
+        got = ops.conv2d(_nhwc(x, torch.float32), pw)           # passes the domain check
+        ref = F.conv2d(x.double(), w.double(), None, padding=1)
+        err = (got.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-6, err
+        for bad in (1.0e5, -3.0e5, 1.0e30):
+            xb = x.clone()
+            xb[0, 9, 8, 8] = bad
+            ops.CONV_DEBUG = 0
+            out = ops.conv2d(_nhwc(xb, torch.float32), pw)
+            assert torch.isfinite(out).all(), f"input {bad:g} under policy {policy} gave a non-finite output"
+            if policy != "generic":                              # (the generic kernel never splits activations: it stays exact)
+                # saturation: the out-of-domain element acts as hi + lo with both halves clamped to +-65504
+                sat = max(min(bad, 65504.0), -65504.0)
+                sat = sat + max(min(bad - sat, 65504.0), -65504.0)
+                xs = xb.clone()
+                xs[0, 9, 8, 8] = sat
+                refs = F.conv2d(xs.double(), w.double(), None, padding=1)
+                errs = (out.permute(0, 3, 1, 2).double().cpu() - refs).abs().max().item() / refs.abs().max().item()
+                assert errs < 1e-3, (bad, errs)
+            ops.CONV_DEBUG = 2
+            with pytest.raises(NlcError, match="outside the domain"):
+                ops.conv2d(_nhwc(xb, torch.float32), pw)
+        ops.CONV_DEBUG = 2
+        xn = x.clone()
+        xn[0, 0, 0, 0] = float("nan")
+        with pytest.raises(NlcError, match="outside the domain"):
+            ops.conv2d(_nhwc(xn, torch.float32), pw)
+    finally:
+        ops.CONV_POLICY, ops.CONV_DEBUG = old, old_dbg
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DTYPE_IDS)
@@ -993,8 +1064,6 @@ RESUPS_CASES = [
     (2, 64, 16, 16, 128, "no_halo", torch.bfloat16),     # conv_fast<9>, hot epilogue
     (16, 128, 8, 8, 128, "auto", torch.bfloat16),        # conv_fast<9> + split-K (last-arriver reduction)
     (2, 40, 12, 20, 24, "generic", torch.bfloat16),      # generic implicit GEMM
-    (2, 64, 32, 64, 128, "wide", torch.bfloat16),
-    (2, 64, 32, 32, 256, "tall", torch.bfloat16),
     (2, 32, 16, 16, 64, "auto", torch.float32),          # f32 parity path
 ]
 
@@ -1003,8 +1072,6 @@ RESUPS_CASES = [
 def test_conv2d_residual_read_nearest_2x_upsampled(case):
     """nlc_conv_desc.res_upsample2x: out = conv(x) + upsample2x(res_small) - the skip branch of an up-sampling ResBlock
     (src/unet_adm.py:186-190) read in place by every epilogue that takes a residual."""
-    if case[5] in ("wide", "tall"):
-        _need_experiments()
     from diffusion_nlc_amd import ops
     B, Cin, H, W, Cout, policy, dtype = case
     g = torch.Generator().manual_seed(43)
@@ -1023,170 +1090,3 @@ def test_conv2d_residual_read_nearest_2x_upsampled(case):
         ops.CONV_POLICY = old
     _close(got.permute(0, 3, 1, 2), ref, _tol(dtype), f"conv2d res_upsample2x ({policy})")
     assert torch.equal(got, same)                 # identical arithmetic to the materialised upsample
-
-
-GNTALL_CASES = [
-    dict(B=2, Cin=128, H=32, W=48, Cout=256, split=64, silu=True, res=True),          # concat input (a group of four k-blocks spans both), edge + interior patches
-    dict(B=1, Cin=384, H=16, W=16, Cout=256, silu=False),                               # one patch per image; three coefficient groups
-    dict(B=2, Cin=128, H=16, W=32, Cout=512, silu=True, ups=True),                      # fused nearest-2x upsample of the normalised input, 2 N-tiles
-    dict(B=1, Cin=128, H=256, W=256, Cout=256, silu=True, emb=True),                    # 256 tiles; cross-tile streams over image-constant coefficients
-    dict(B=3, Cin=256, H=64, W=64, Cout=256, silu=True),                                # 48 tiles per image: the coefficient stage flips at image boundaries
-]
-
-
-@pytest.mark.parametrize("case", GNTALL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d_tall_kernel_with_groupnorm_prologue(case):
-    """conv_tall_kernel<.., GN>: conv(act(a[b][c] x + b[b][c])) with the affine map (+SiLU) applied to the halo rows in LDS, once per
-    patch for all 256 output channels - against F.conv2d of the explicitly normalised input (zero padding AFTER the normalisation)."""
-    _need_experiments()
-    from diffusion_nlc_amd import ops
-    g = torch.Generator().manual_seed(79)
-    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
-    x = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.2
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
-    b = torch.randn(Cout, generator=g) * 0.1
-    a_ = torch.rand(B, Cin, generator=g) + 0.5
-    b_ = torch.randn(B, Cin, generator=g) * 0.3
-    xr = _rt(x, torch.bfloat16)
-    y = xr * a_[:, :, None, None] + b_[:, :, None, None]
-    if case.get("silu"):
-        y = F.silu(y)
-    y = _rt(y, torch.bfloat16)                                       # the prologue stores bf16 back into LDS
-    if case.get("ups"):
-        y = F.interpolate(y, scale_factor=2, mode="nearest")
-    ref = F.conv2d(y, _rt(w, torch.bfloat16), b, padding=1)
-    emb = res = None
-    if case.get("emb"):
-        emb = torch.randn(B, Cout, generator=g)
-        ref = ref + emb[:, :, None, None]
-    if case.get("res"):
-        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
-        ref = ref + _rt(res, torch.bfloat16)
-    coef = torch.zeros(B * Cin * 2 + 128)
-    coef[:B * Cin * 2] = torch.stack([a_, b_], dim=-1).reshape(-1)
-    coef = coef.to(_dev())
-    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
-    split = case.get("split")
-    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
-    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
-    old = ops.CONV_POLICY
-    ops.CONV_POLICY = "tall"
-    try:
-        kw = dict(x1=x1, upsample2x=bool(case.get("ups")))
-        assert ops.conv2d(x0, pw, query_prologue=True, **kw)
-        got = ops.conv2d(x0, pw, gn_coef=coef, gn_act=1 if case.get("silu") else 0, emb=None if emb is None else emb.to(_dev()),
-                         res=None if res is None else _nhwc(res, torch.bfloat16), **kw)
-        torch.cuda.synchronize()
-    finally:
-        ops.CONV_POLICY = old
-    st = getattr(got, "_nlc_stats", None)
-    assert st is not None and st.shape[1] == (ref.shape[2] // 16) * (ref.shape[3] // 16) * 4, "the tall kernel did not take this launch"
-    _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (tall kernel, GroupNorm prologue)")
-
-
-TALL_CASES = [
-    dict(B=2, Cin=128, H=16, W=16, Cout=256, split=64, emb=True, res=True, scale=math.sqrt(0.5)),       # one patch per image, concat input
-    dict(B=1, Cin=64, H=32, W=48, Cout=512, bias=False),                                                  # interior + border patches, 2 N-tiles
-    dict(B=2, Cin=64, H=8, W=16, Cout=256, ups=True, res=True),                                           # fused nearest-2x upsample
-    dict(B=3, Cin=192, H=16, W=32, Cout=256, emb=True),                                                   # 6 k-blocks (three loop trips)
-    dict(B=2, Cin=128, H=256, W=256, Cout=256, res=True),                                                 # 512 tiles: two per persistent workgroup
-]
-
-
-@pytest.mark.parametrize("case", TALL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d_tall_kernel(case):
-    """conv_tall_kernel (256-pixel x 256-channel tiles, 32-channel k-blocks, ring of four weight fragments) forced for shapes of
-    every kind it takes, against F.conv2d; plus its ride-along statistics."""
-    _need_experiments()
-    from diffusion_nlc_amd import ops
-    g = torch.Generator().manual_seed(37)
-    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
-    b = torch.randn(Cout, generator=g) * 0.1 if case.get("bias", True) else None
-    xr = _rt(x, torch.bfloat16)
-    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if case.get("ups") else xr
-    ref = F.conv2d(xin, _rt(w, torch.bfloat16), b, padding=1)
-    emb = res = None
-    if case.get("emb"):
-        emb = torch.randn(B, Cout + 8, generator=g)
-        ref = ref + emb[:, :Cout, None, None]
-    if case.get("res"):
-        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
-        ref = ref + _rt(res, torch.bfloat16)
-    ref = ref * case.get("scale", 1.0)
-    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
-    split = case.get("split")
-    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
-    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
-    old = ops.CONV_POLICY
-    ops.CONV_POLICY = "tall"
-    try:
-        got = ops.conv2d(x0, pw, x1=x1, upsample2x=bool(case.get("ups")), emb=None if emb is None else emb.to(_dev())[:, :],
-                         res=None if res is None else _nhwc(res, torch.bfloat16), out_scale=case.get("scale", 1.0))
-        torch.cuda.synchronize()
-    finally:
-        ops.CONV_POLICY = old
-    Ho, Wo = ref.shape[2], ref.shape[3]
-    st = getattr(got, "_nlc_stats", None)
-    assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 16) * 4, Cout // 8, 2), "the tall kernel did not take this launch"
-    _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (tall kernel)")
-    ch = got.float().cpu().view(B, Ho * Wo, Cout // 8, 8).double()
-    tot = st.double().sum(dim=1).cpu()
-    s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
-    assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
-    assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3
-
-
-WIDE_CASES = [
-    dict(B=2, Cin=128, H=16, W=32, Cout=128, split=64, emb=True, res=True, scale=math.sqrt(0.5)),       # one patch per image, concat input
-    dict(B=1, Cin=64, H=32, W=64, Cout=256, bias=False),                                                  # interior + border patches, 2 N-tiles
-    dict(B=2, Cin=64, H=8, W=16, Cout=128, ups=True, res=True),                                           # fused nearest-2x upsample
-    dict(B=3, Cin=192, H=16, W=64, Cout=128, emb=True),                                                   # 6 k-blocks (three loop trips)
-    dict(B=2, Cin=128, H=256, W=256, Cout=256, res=True),                                                 # 512 tiles: two per persistent workgroup
-]
-
-
-@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d_wide_kernel(case):
-    """conv_wide_kernel (512-pixel x 128-channel tiles, one wave per SIMD, 32-channel k-blocks, buffer-load halo DMA with
-    out-of-range zero fill) forced for shapes of every kind it takes, against F.conv2d; plus its ride-along statistics."""
-    _need_experiments()
-    from diffusion_nlc_amd import ops
-    g = torch.Generator().manual_seed(31)
-    B, Cin, H, W, Cout = (case[k] for k in ("B", "Cin", "H", "W", "Cout"))
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
-    b = torch.randn(Cout, generator=g) * 0.1 if case.get("bias", True) else None
-    xr = _rt(x, torch.bfloat16)
-    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if case.get("ups") else xr
-    ref = F.conv2d(xin, _rt(w, torch.bfloat16), b, padding=1)
-    emb = res = None
-    if case.get("emb"):
-        emb = torch.randn(B, Cout + 8, generator=g)
-        ref = ref + emb[:, :Cout, None, None]
-    if case.get("res"):
-        res = torch.randn(B, Cout, ref.shape[2], ref.shape[3], generator=g)
-        ref = ref + _rt(res, torch.bfloat16)
-    ref = ref * case.get("scale", 1.0)
-    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
-    split = case.get("split")
-    x0 = _nhwc(x[:, :split] if split else x, torch.bfloat16)
-    x1 = _nhwc(x[:, split:], torch.bfloat16) if split else None
-    old = ops.CONV_POLICY
-    ops.CONV_POLICY = "wide"
-    try:
-        got = ops.conv2d(x0, pw, x1=x1, upsample2x=bool(case.get("ups")), emb=None if emb is None else emb.to(_dev())[:, :],
-                         res=None if res is None else _nhwc(res, torch.bfloat16), out_scale=case.get("scale", 1.0))
-        torch.cuda.synchronize()
-    finally:
-        ops.CONV_POLICY = old
-    Ho, Wo = ref.shape[2], ref.shape[3]
-    st = getattr(got, "_nlc_stats", None)
-    assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 32) * 4, Cout // 8, 2), "the wide kernel did not take this launch"
-    _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (wide kernel)")
-    ch = got.float().cpu().view(B, Ho * Wo, Cout // 8, 8).double()
-    tot = st.double().sum(dim=1).cpu()
-    s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
-    assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
-    assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3

@@ -81,6 +81,14 @@ def test_bench_self_launches_its_ranks_under_gloo():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 32 and "DRY RUN" in line["metric"]
+    # diagnosability of the first multi-GPU run: the world size the process group really had, and every rank's phase times
+    assert line["ranks_seen"] == 2
+    pr = line["per_rank_seconds"]
+    assert set(pr) == {"timed_region", "sampling", "all_gather", "final_barrier", "setup_untimed", "model_build_untimed"}
+    assert all(len(v) == 2 for v in pr.values())
+    for r_ in range(2):
+        assert abs(pr["sampling"][r_] + pr["all_gather"][r_] + pr["final_barrier"][r_] - pr["timed_region"][r_]) < 5e-3
+    assert abs(max(pr["timed_region"]) * 1e3 / 2 - line["ms_per_step"]) < 1.0          # value = max over ranks
     # a rank that dies must fail the whole command
     bad = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=600)
