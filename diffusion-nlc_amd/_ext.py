@@ -114,13 +114,13 @@ SIGNATURES = {
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_prologue_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
-    "nlc_groupnorm_coef": (C.c_int, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "nlc_groupnorm_coef": (C.c_int, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "nlc_conv_first_stats_partials": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),
     "nlc_groupnorm_workspace_bytes": (C.c_int64, [_i, _i, _i, _i]),
     "nlc_groupnorm": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
-    "nlc_groupnorm_prestats": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
-    "nlc_groupnorm_pool2x2": (C.c_int, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "nlc_groupnorm_prestats": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "nlc_groupnorm_pool2x2": (C.c_int, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "nlc_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "nlc_avgpool2x2": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "nlc_upsample2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

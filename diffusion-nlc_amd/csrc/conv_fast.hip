@@ -403,7 +403,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         }
     }
     if (n >= p.Cout) return;
-    const bool pix_stats = p.ksplit > 1;             // split launches emit one statistics partial per PIXEL (tiles may straddle images)
+    const bool pix_stats = p.ksplit > 1 || (HWo % BM) != 0;     // tiles may straddle images: statistics per 16-pixel row (emit_pix)
 
     // ---- epilogue straight from registers
     const bool vec_ok = (p.Cout % PER) == 0;
@@ -420,6 +420,28 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     }
     Stat16 st16;                                                // ride-along GroupNorm statistics: this lane's 16 channels, 4 pixels
     st16.zero();
+    // sum over the 16 pixel lanes of a DPP row, VALU only (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): an all-reduce
+    auto row16_sum = [](float x) {
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+        return x;
+    };
+    // split launches: a 128-pixel tile may straddle images, a 16-pixel row (the lanes fr = 0..15, consecutive m) cannot when both the
+    // map and the launch are whole multiples of 16 pixels (launch-uniform; every network shape) - the row is then reduced and added to
+    // its image's totals with one atomic instruction; otherwise every lane adds its own pixel
+    const bool rows_ok = (p.M & 15) == 0 && (HWo & 15) == 0;
+    auto emit_pix = [&](Stat16& st, int m) {
+        const int b = p.div_hwo.div(m);
+        if (rows_ok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { st.s[k] = row16_sum(st.s[k]); st.q[k] = row16_sum(st.q[k]); }
+            st.emit_row(p.stats, b, p.Cout, n, p.stats_gran, fr);
+        } else {
+            st.emit_lane(p.stats, b, p.Cout, n, p.stats_gran);
+        }
+    };
     bool done = false;
     if constexpr (sizeof(T) == 2) {
         // hot path (bf16, whole 16-channel slice, NHWC, no per-image embedding): option switches hoisted out of the
@@ -474,10 +496,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                 if (has_stats) {         // of the STORED (rounded) values - what the GroupNorm that follows reads
                     if (pix_stats) st16.zero();
                     st16.add_chunk<T>(0, pk0); st16.add_chunk<T>(1, pk1);
-                    if (pix_stats) {     // [b][pixel][chunk][{sum, sumsq}], stats_P = Hout * Wout
-                        const int b = p.div_hwo.div(m);
-                        st16.store(p.stats, (int64_t)b * p.stats_P + (m - b * HWo), p.Cout, n, p.stats_gran);
-                    }
+                    if (pix_stats) emit_pix(st16, m);       // split launches: a tile may straddle images -> per 16-pixel row
                 }
             }
             done = true;
@@ -542,7 +561,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
                     }
                 }
                 if constexpr (sizeof(T) == 2) {
-                    if (p.stats && pix_stats) st16.store(p.stats, (int64_t)b * p.stats_P + (m - b * HWo), p.Cout, n, p.stats_gran);
+                    if (p.stats && pix_stats) emit_pix(st16, m);
                 }
             } else {
 #pragma unroll
@@ -557,21 +576,9 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
     }
     if constexpr (sizeof(T) == 2) {
         if (p.stats && !pix_stats) {       // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
-            // sum over the 16 pixel lanes of a DPP row, VALU only (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
-            auto row16_sum = [](float x) {
-                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
-                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
-                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
-                x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
-                return x;
-            };
 #pragma unroll
             for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
-            if (fr == 0) {
-                const int b = m0 / HWo;
-                const int part = ((m0 - b * HWo) / BM) * 2 + wm;
-                st16.store(p.stats, (int64_t)b * p.stats_P + part, p.Cout, n, p.stats_gran);
-            }
+            st16.emit_row(p.stats, m0 / HWo, p.Cout, n, p.stats_gran, fr);
         }
     }
 }
@@ -622,14 +629,10 @@ int nlc_conv_fast_ksplit(const KParams& p, int dtype) {
     return s < 2 ? 1 : s;
 }
 
-// GroupNorm statistics ride along on the fast path when the N-tiles are whole and the output is bf16 NHWC: from the conv
-// epilogue if every 128-pixel tile lies inside one image, per pixel from the last-arriving workgroup when K is split
+// GroupNorm statistics ride along on the fast path when the N-tiles are whole and the output is 16-bit NHWC: per tile from the conv
+// epilogue if every 128-pixel tile lies inside one image, else (and from the last-arriving workgroup when K is split) per 16-pixel row
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype) {
-    if (!nlc_is16(dtype) || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0 || !fast_shape(p)) return 0;
-    const int HWo = p.Hout * p.Wout;
-    if (nlc_conv_fast_ksplit(p, dtype) > 1) return HWo;          // split-K: the last-arriving workgroup emits one partial per pixel
-    if (HWo % BM) return 0;
-    return (HWo / BM) * 2;
+    return (nlc_is16(dtype) && p.out_mode == NLC_OUT_NHWC && (p.Cout % BN) == 0 && fast_shape(p)) ? 1 : 0;
 }
 
 // workspace of a split launch: the arrival counters (4 KiB in front; tiles < 512) + ks x (whole 128 x 128 tiles) f32 partial sums

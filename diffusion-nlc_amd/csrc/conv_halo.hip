@@ -377,15 +377,12 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{cadd[j * 4], cadd[j * 4 + 1], cadd[j * 4 + 2], cadd[j * 4 + 3]};
     };
-    // reduce a lane's statistics over the 16 pixel lanes (fr) of its quarter-wave in a fixed order, then one 16-byte store per
-    // (patch, M-wave, 16-channel slice): stats[b][partial][chunk][{sum, sumsq}]
+    // all-reduce a lane's statistics over the 16 pixel lanes (fr) of its quarter-wave in a fixed order, then every lane adds one
+    // limb of the slice's totals: ONE atomic instruction per wave and tile (Stat16::emit_row, conv_params.h)
     auto emit_stats = [&](Stat16& st16, const TileH& t, int n) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
-        if (fr == 0) {
-            const int part = ((t.y0 / PATCH) * tiles_x + t.x0 / PATCH) * 4 + wm;
-            st16.store(p.stats, (int64_t)t.tb * p.stats_P + part, p.Cout, n, p.stats_gran);
-        }
+        st16.emit_row(p.stats, t.tb, p.Cout, n, p.stats_gran, fr);
     };
     // Pins the accumulator initialisation where it is written.  Left free, the compiler sank it (and the wait for the bias loads
     // that feed it) past the loop back-edge, where its wait-count pass assumes the worst predecessor: `s_waitcnt vmcnt(0)` at the top
@@ -1049,12 +1046,12 @@ int nlc_conv_halo_prologue_ok(const KParams& p, int dtype) {
     return dtype == NLC_BF16 && halo_plain_ok(p, dtype) ? 1 : 0;
 }
 
-// GroupNorm statistics ride along when the halo kernel runs in bf16 with NHWC output and whole 128-channel N-tiles: four partials
-// per 16x16 patch (split-K launches too: from the epilogue of the workgroup that arrives last at the tile)
+// GroupNorm statistics ride along when the halo kernel runs in 16 bits with NHWC output and whole 128-channel N-tiles (split-K
+// launches too: from the epilogue of the workgroup that arrives last at the tile)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype) {
     if (!nlc_is16(dtype) || p.out_mode != NLC_OUT_NHWC || (p.Cout % BN) != 0) return 0;
     if (nlc_conv_halo_ksplit(p, dtype) <= 1 && !halo_plain_ok(p, dtype)) return 0;
-    return (p.Hout / PATCH) * (p.Wout / PATCH) * 4;
+    return 1;
 }
 
 // 3x3 / stride 1 / pad 1 (optionally on the nearest-2x upsampled input), output H and W multiples of 16, enough tiles to fill the chip.

@@ -266,7 +266,7 @@ static void fill_params(const nlc_conv_desc* d, KParams& p) {
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
     p.ksplit = 1; p.partial = nullptr;
-    p.stats = nullptr; p.stats_P = 0;
+    p.stats = nullptr;
     p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math; p.w_scale = d->w_scale;
     p.policy = d->policy; p.tuning = d->tuning;
     p.stats_gran = d->stats_granule == 4 ? 4 : 8;
@@ -405,8 +405,9 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             Pfast = Phalo > 0 ? 0 : nlc_conv_fast_stats_partials(p, dtype);
             const int P = nlc_conv_narrow_ok(p, dtype) ? 0 : (Phalo > 0 ? Phalo : Pfast);
             NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
-            NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * P * (p.Cout / p.stats_gran) * 2 * (int64_t)sizeof(float), "nlc_conv2d: stats_out too small");
-            p.stats = (float*)d->stats_out; p.stats_P = P;
+            NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * (p.Cout / p.stats_gran) * 4 * (int64_t)sizeof(long long), "nlc_conv2d: stats_out too small");
+            NLC_REQUIRE((reinterpret_cast<uintptr_t>(d->stats_out) & 7) == 0, "nlc_conv2d: stats_out must be 8-byte aligned");
+            p.stats = (long long*)d->stats_out;
         }
         NLC_REQUIRE(!p.gn_coef || nlc_conv_halo_prologue_ok(p, dtype),
                     "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue (ask nlc_conv2d_prologue_supported first)");
@@ -422,7 +423,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         rc = nlc_conv_halo_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         p.ksplit = 1; p.partial = nullptr;
-        if (!Pfast) { p.stats = nullptr; p.stats_P = 0; }
+        if (!Pfast) p.stats = nullptr;
         if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace
             const int ks = nlc_conv_fast_ksplit(p, dtype);
             if (ks > 1 && d->workspace_bytes >= nlc_conv_fast_split_bytes(p, ks)) {
@@ -430,10 +431,6 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
                 if (d->debug & 1) { const int cr = check_counters(p, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
             }
         }
-        // the statistics layout was sized for the kernel that nlc_conv2d_stats_partials predicted (split-K reduce: one
-        // partial per pixel; otherwise two per 128-pixel tile): the workspace decides which one actually runs
-        NLC_REQUIRE(!p.stats || (nlc_conv_fast_ksplit(p, dtype) > 1) == (p.ksplit > 1),
-                    "nlc_conv2d: stats_out on a split-K shape needs the workspace of nlc_conv2d_workspace_bytes");
         rc = nlc_conv_fast_dispatch(p, dtype, (hipStream_t)stream);
         if (rc != NLC_EUNSUPPORTED) return rc;
         p.ksplit = 1; p.partial = nullptr;

@@ -42,8 +42,8 @@ struct KParams {
     int M, MT, NT;
     int ksplit;         // conv_fast only: >1 = split the channel blocks over blockIdx.y, raw f32 partials to `partial`
     float* partial;     // split-K partial sums + arrival counters (caller workspace); reduced by the last-arriving workgroup of a tile
-    float* stats;       // conv_halo / conv_fast (bf16, NHWC out, Cout % 128 == 0) or NULL: [B][stats_P][Cout/8][2] = per 8-channel
-    int stats_P;        //   chunk (sum, sum of squares) of the STORED (bf16-rounded) outputs, one partial per (patch, M-wave)
+    long long* stats;   // conv_halo / conv_fast (16-bit, NHWC out, Cout % 128 == 0) or NULL: [B][Cout/gran][4] 64-bit accumulators of the
+                        //   (sum, sum of squares) of the STORED (rounded) outputs per chunk (Stat16: hi / lo limbs), added to atomically
     int policy;         // NLC_CONV_* kernel-selection policy of this call (nlc_conv_desc.policy)
     int tuning;         // A/B switches (nlc_conv_desc.tuning)
     const float* gn_coef; int gn_act;   // conv_halo (bf16) only: input = act(a x + b) applied in LDS (nlc_conv_desc.gn_coef)
@@ -87,15 +87,45 @@ struct Stat16 {
             }
         }
     }
-    // values already reduced over whatever shares the partial; n = the lane's first channel
-    __device__ __forceinline__ void store(float* stats, int64_t row /* b * P + partial */, int Cout, int n, int gran) const {
-        if (gran == 4) {
-            float* dst = stats + (row * (Cout >> 2) + (n >> 2)) * 2;
-            *reinterpret_cast<float4*>(dst) = float4{s[0], q[0], s[1], q[1]};
-            *reinterpret_cast<float4*>(dst + 4) = float4{s[2], q[2], s[3], q[3]};
-        } else {
-            float* dst = stats + (row * (Cout >> 3) + (n >> 3)) * 2;
-            *reinterpret_cast<float4*>(dst) = float4{s[0] + s[1], q[0] + q[1], s[2] + s[3], q[2] + q[3]};
+    // ---- totals (include/nlc_hip.h, "GroupNorm statistics ride along"): every (image, chunk) owns four 64-bit accumulators
+    //      (sum.hi, sum.lo, sumsq.hi, sumsq.lo) that ALL contributions of a launch are added into with integer atomics.  A
+    //      contribution v (an f32 partial sum, exact in f64) is split into hi = floor(v) and lo = floor((v - hi) * 2^44): integer
+    //      addition is associative, so the totals do not depend on the order in which workgroups arrive - bit-reproducible without a
+    //      partials array, a fixed-order reduction pass or a finalize launch.  Resolution 2^-44 per contribution (5.7e-14), range
+    //      +-2^63; the consumer (groupnorm.hip: gn_channel_coefs) reads value = hi + lo * 2^-44 in f64.
+    static constexpr double LIMB = 17592186044416.0;           // 2^44
+    static __device__ __forceinline__ void limbs(float v, long long& hi, long long& lo) {
+        const double d = (double)v, fl = floor(d);
+        hi = (long long)fl;
+        lo = (long long)((d - fl) * LIMB);
+    }
+    // After a 16-lane all-reduce (every lane of the row holds the row's sums for its 16 channels from n): lane `fr` of the row adds
+    // ONE limb - its index within the slice's 16 (per-4 granules) or 8 (per-8 chunks) accumulators - so that a wave issues a single
+    // atomic instruction per tile.
+    __device__ __forceinline__ void emit_row(long long* tot, int b, int Cout, int n, int gran, int fr) const {
+        const float v8[8] = {s[0] + s[1], q[0] + q[1], s[2] + s[3], q[2] + q[3], 0.f, 0.f, 0.f, 0.f};
+        const float v4[8] = {s[0], q[0], s[1], q[1], s[2], q[2], s[3], q[3]};
+        const int vi = fr >> 1;
+        float v = gran == 4 ? v4[0] : v8[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v = (vi == k) ? (gran == 4 ? v4[k] : v8[k]) : v;
+        if (gran != 4 && fr >= 8) return;
+        long long hi, lo;
+        limbs(v, hi, lo);
+        long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4 + fr;
+        atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)((fr & 1) ? lo : hi));
+    }
+    // one lane alone adds everything it holds (launches whose 16-pixel rows may straddle two images: never taken by the networks)
+    __device__ __forceinline__ void emit_lane(long long* tot, int b, int Cout, int n, int gran) const {
+        const float v8[4] = {s[0] + s[1], q[0] + q[1], s[2] + s[3], q[2] + q[3]};
+        const float v4[8] = {s[0], q[0], s[1], q[1], s[2], q[2], s[3], q[3]};
+        long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4;
+        const int nv = gran == 4 ? 8 : 4;
+        for (int k = 0; k < nv; ++k) {
+            long long hi, lo;
+            limbs(gran == 4 ? v4[k] : v8[k], hi, lo);
+            atomicAdd(reinterpret_cast<unsigned long long*>(dst + 2 * k), (unsigned long long)hi);
+            atomicAdd(reinterpret_cast<unsigned long long*>(dst + 2 * k + 1), (unsigned long long)lo);
         }
     }
 };

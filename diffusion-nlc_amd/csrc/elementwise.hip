@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NT) void conv_first_kernel(const float* __restrict_
 //      f32 state, each of the 4 waves multiplies it with its 64 channels (operands swapped: a lane ends up with 16
 //      consecutive channels of one pixel), adds the bias and stores 16-byte chunks.  HBM-bound on the output write
 //      (the VALU version ran at 32 TFLOP/s of f32 FMAs: 0.45 ms for the 537 MB of ADM-256's first layer).
-//      GroupNorm statistics of the output ride along (per 8-channel chunk (sum, sumsq), one partial per workgroup).
+//      GroupNorm statistics of the output ride along (per chunk (sum, sumsq) totals, added atomically once per workgroup).
 constexpr int F1_PIX = 64;
 constexpr int F1_LD = 80;          // LDS bytes per patch row: 64 B of k + 16 B pad (conflict-free 16-byte fragment reads)
 template <typename T>
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              T* __restrict__ out, int Cin, int H, int W, int Cout,
                                                              int KH, int KW, int tiles_per_blk, int blks_per_img,
-                                                             float* __restrict__ stats, int stats_gran) {
+                                                             long long* __restrict__ stats, int stats_gran) {
     __shared__ __attribute__((aligned(16))) char patch[2][F1_PIX * F1_LD];
     const int K = KH * KW * Cin;
     const int HW = H * W;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NT) void conv_first_mfma_kernel(const float* __rest
         for (int o = 1; o < 16; o <<= 1)
 #pragma unroll
             for (int q = 0; q < 4; ++q) { st16.s[q] += __shfl_xor(st16.s[q], o, 64); st16.q[q] += __shfl_xor(st16.q[q], o, 64); }
-        if (fr == 0 && n < Cout) st16.store(stats, (int64_t)b * blks_per_img + blk, Cout, n, stats_gran);
+        if (n < Cout) st16.emit_row(stats, b, Cout, n, stats_gran, fr);          // totals: one atomic instruction per wave
     }
 }
 
@@ -375,7 +375,8 @@ extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const 
         if (want_stats) {
             NLC_REQUIRE(nb > 0 && (Cout % 16) == 0 && ((int64_t)H * W) % F1_PIX == 0,
                         "nlc_conv_first: stats_out given but this launch does not emit statistics (ask nlc_conv_first_stats_partials)");
-            NLC_REQUIRE(stats_bytes >= (int64_t)B * nb * (Cout / gran) * 2 * (int64_t)sizeof(float), "nlc_conv_first: stats_out too small");
+            NLC_REQUIRE(stats_bytes >= (int64_t)B * (Cout / gran) * 4 * (int64_t)sizeof(long long), "nlc_conv_first: stats_out too small");
+            NLC_REQUIRE((reinterpret_cast<uintptr_t>(stats_out) & 7) == 0, "nlc_conv_first: stats_out must be 8-byte aligned");
         }
         if (nb > 0) {
             const int ntile = (int)(((int64_t)H * W + F1_PIX - 1) / F1_PIX);
@@ -383,7 +384,7 @@ extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const 
             const int nblk = (ntile + tpb - 1) / tpb;
             NLC_REQUIRE(!want_stats || nblk == nb, "nlc_conv_first: internal: partial count mismatch");
             NLC_SWITCH_16(dtype, hipLaunchKernelGGL(conv_first_mfma_kernel<T16>, dim3(nblk, B), dim3(NT), 0, (hipStream_t)stream, x_nchw, in_scale, w,
-                                                    bias, (T16*)out_nhwc, Cin, H, W, Cout, KH, KW, tpb, nb, (float*)stats_out, gran));
+                                                    bias, (T16*)out_nhwc, Cin, H, W, Cout, KH, KW, tpb, nb, (long long*)stats_out, gran));
             NLC_CHECK_LAUNCH("nlc_conv_first");
             return NLC_OK;
         }

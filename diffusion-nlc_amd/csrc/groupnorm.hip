@@ -16,6 +16,7 @@
 // torch.cat of the reference (src/unet_adm.py:662) is never materialised.
 // y = a*x + b is the same factorisation ATen's CPU group_norm kernel uses.
 #include "common.h"
+#include "conv_params.h"      // Stat16: the fixed-point format of the ride-along statistics totals
 #include <stdlib.h>
 
 namespace {
@@ -39,7 +40,14 @@ struct GNParams {
     int silu;
     char* out;
     double* ws;         // [B][nblk][G][3] = (count, mean, M2)
-    const float* coef;  // [B][C][2] = (a, b) per (image, channel), written by gn_finalize_chunks_kernel, or NULL: the apply threads compute them
+    const float* coef;  // [B][C][2] = (a, b) per (image, channel) or NULL: the apply threads compute them
+    // statistics that rode along in the producing convolutions' epilogues (nlc_conv_desc.stats_out): per source the totals
+    // [B][C_src / tg][4] of 64-bit accumulators (sum.hi, sum.lo, sumsq.hi, sumsq.lo) per tg-channel chunk (conv_params.h: Stat16), or NULL
+    const long long* tot0; const long long* tot1; int tg0, tg1;
+    int tsh0, tsh1;     // log2 of the granules (2 | 3)
+    double invN;        // 1 / (HW * gs): elements per group
+    int vec_affine;     // gamma / beta / scale / shift (those present) are 16-byte aligned incl. the row stride: float4 loads
+    FastDiv div_gs;     // channel -> group
 };
 
 template <typename T>
@@ -286,88 +294,47 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const GNParams p, float
     }
 }
 
-// Statistics that rode along in the producing convolutions' epilogues (nlc_conv_desc.stats_out): per source a float
-// array [B][P][C_src/8][2] of (sum, sum of squares) per 8-channel chunk and partial.  One workgroup per (group, image)
-// adds the group's chunks over all partials in f64 in a fixed order (thread t takes partials t, t+256, ...; tree over
-// the threads) -> (mean, rstd) in the same stat[b][g] table gn_finalize writes.
-struct GNCoefOut {        // optional second product of gn_finalize_chunks_kernel: y = a[b][c] x + b[b][c] folded per channel
-    float* coef;          // [B][C][2] or NULL
-    const float* gamma; const float* beta; const float* scale; const float* shift; int ss_stride;
-};
-// TPG threads per group (a power of two, 8 ... 256, chosen by the host from the amount of work per group), NT / TPG groups per
-// workgroup: with one workgroup per (group, image) a batch of 200 32x32 maps launched 6400 workgroups of 256 threads for 16 loads
-// each (10 us per launch, 6 % of an EDM network evaluation).  Fixed summation order: thread l of a group takes items l, l + TPG, ...
-// of the (chunk, partial) list, then a tree over the group's threads.
-__global__ __launch_bounds__(NT) void gn_finalize_chunks_kernel(const float* __restrict__ s0, int P0, int C0,
-                                                              const float* __restrict__ s1, int P1, int C1,
-                                                              int gs, int G, int HW, float eps, float* __restrict__ stat,
-                                                              const GNCoefOut co, int TPG, int gran0, int gran1) {
-    __shared__ double red[2][NT];
-    __shared__ float s_mean[NT / 8], s_rstd[NT / 8];
-    const int gpw = NT / TPG;                                  // groups per workgroup
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int gl = tid / TPG, l = tid - gl * TPG;
-    const int g = blockIdx.x * gpw + gl;
-    // each source carries its statistics per gran0 / gran1 (4 or 8) channels; a group is a whole number of chunks of either source
-    // (host-checked: gs and C0 are multiples of both granules), so walking the group's channels in steps of the source's own granule
-    // visits every chunk of the group exactly once
-    const int nq0 = C0 / gran0, nq1 = C1 > 0 ? C1 / gran1 : 0;
-    double a = 0.0, c = 0.0;
-    if (g < G) {
-        int ch = g * gs;
-        const int ch1 = ch + gs;
-        while (ch < ch1) {
-            const bool second = ch >= C0;
-            const float* src = second ? s1 : s0;
-            const int gr = second ? gran1 : gran0;
-            const int P = second ? P1 : P0, nq = second ? nq1 : nq0, qq = (second ? ch - C0 : ch) / gr;
-            const float* base = src + ((int64_t)b * P * nq + qq) * 2;
-            for (int pp = l; pp < P; pp += TPG) {
-                const float2 v = *reinterpret_cast<const float2*>(base + (int64_t)pp * nq * 2);
-                a += (double)v.x; c += (double)v.y;
-            }
-            ch += gr;
+// (mean, rstd) of group g of image b from the totals that rode along with the producing convolutions (GNParams::tot0 / tot1): the
+// group's chunks - over both sources of a concatenated input; a group is a whole number of chunks of either source (host-checked) -
+// added in f64 (value = hi + lo * 2^-44: exact integers, so no order dependence upstream), var = E[x^2] - mean^2 in f64.
+// Every apply thread evaluates this for the one or two groups its channels lie in: 1 ... 8 32-byte loads - there is no partials
+// array, no reduction pass and no finalize launch between a convolution and the normalisation that follows it.
+__device__ __forceinline__ void gn_group_from_totals(const GNParams& p, int b, int g, float& mean, float& rstd) {
+    double S = 0.0, Q = 0.0;
+    const int ch = g * p.gs, ch1 = ch + p.gs;
+    auto add = [&](const long long* tot, int nq, int first_chunk, int nchunk) {      // the group's chunks of one source are contiguous
+        const longlong2* t = reinterpret_cast<const longlong2*>(tot + ((int64_t)b * nq + first_chunk) * 4);
+        for (int k = 0; k < nchunk; ++k) {
+            const longlong2 ts = t[2 * k], tq = t[2 * k + 1];
+            S += (double)ts.x + (double)ts.y * (1.0 / Stat16::LIMB);
+            Q += (double)tq.x + (double)tq.y * (1.0 / Stat16::LIMB);
         }
+    };
+    const int e0 = min(ch1, p.C0), s1 = max(ch, p.C0);
+    if (ch < e0) add(p.tot0, p.C0 >> p.tsh0, ch >> p.tsh0, (e0 - ch) >> p.tsh0);
+    if (s1 < ch1) add(p.tot1, p.C1 >> p.tsh1, (s1 - p.C0) >> p.tsh1, (ch1 - s1) >> p.tsh1);
+    const double mean_d = S * p.invN;
+    double var = Q * p.invN - mean_d * mean_d;          // f64: E[x^2] - mean^2 keeps ~9 digits after the cancellation
+    if (var < 0.0) var = 0.0;
+    mean = (float)mean_d;
+    rstd = rsqrtf((float)(var + (double)p.eps));         // (the totals describe 16-bit tensors: a 1-ulp f32 reciprocal square root is ample)
+}
+
+// nlc_groupnorm_coef: the (a, b) table of GroupNorm (+FiLM) per (image, channel) from the totals, for a convolution that applies the
+// normalisation in its LDS prologue (nlc_conv_desc.gn_coef).  One thread per (image, channel).
+__global__ __launch_bounds__(NT) void gn_coef_from_totals_kernel(const GNParams p, float* __restrict__ coef) {
+    const int b = blockIdx.y, ch = blockIdx.x * NT + threadIdx.x;
+    if (ch >= p.C) return;
+    float mean, rstd;
+    gn_group_from_totals(p, b, p.div_gs.div(ch), mean, rstd);
+    float aa = rstd * (p.gamma ? p.gamma[ch] : 1.f);
+    float bb = (p.beta ? p.beta[ch] : 0.f) - mean * aa;
+    if (p.scale) {
+        const float sc = 1.f + p.scale[(int64_t)b * p.ss_stride + ch];
+        const float sh = p.shift[(int64_t)b * p.ss_stride + ch];
+        aa *= sc; bb = bb * sc + sh;
     }
-    red[0][tid] = a; red[1][tid] = c;
-    __syncthreads();
-    for (int o = TPG / 2; o > 0; o >>= 1) {
-        if (l < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
-        __syncthreads();
-    }
-    if (l == 0 && g < G) {
-        const double N = (double)HW * gs;
-        const double mean_d = red[0][tid] / N;
-        double var = red[1][tid] / N - mean_d * mean_d;
-        if (var < 0.0) var = 0.0;
-        const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
-        s_mean[gl] = mean; s_rstd[gl] = rstd;
-        if (stat) {
-            stat[((int64_t)b * G + g) * 2 + 0] = mean;
-            stat[((int64_t)b * G + g) * 2 + 1] = rstd;
-        }
-    }
-    if (co.coef) {
-        // the same a / b factorisation gn_apply_fast_kernel evaluates per thread, written once per (image, channel): for the apply
-        // kernel (four 16-byte loads instead of the per-channel algebra) and for a convolution that applies the normalisation in
-        // its LDS prologue (nlc_conv_desc.gn_coef)
-        __syncthreads();
-        const int C = C0 + C1;
-        const int g0 = blockIdx.x * gpw, ng = min(gpw, G - g0);
-        for (int j = tid; j < ng * gs; j += NT) {
-            const int gi = j / gs;
-            const int ch = g0 * gs + j;
-            const float mean = s_mean[gi], rstd = s_rstd[gi];
-            float aa = rstd * (co.gamma ? co.gamma[ch] : 1.f);
-            float bb = (co.beta ? co.beta[ch] : 0.f) - mean * aa;
-            if (co.scale) {
-                const float sc = 1.f + co.scale[(int64_t)b * co.ss_stride + ch];
-                const float sh = co.shift[(int64_t)b * co.ss_stride + ch];
-                aa *= sc; bb = bb * sc + sh;
-            }
-            *reinterpret_cast<float2*>(co.coef + ((int64_t)b * C + ch) * 2) = float2{aa, bb};
-        }
-    }
+    *reinterpret_cast<float2*>(coef + ((int64_t)b * p.C + ch) * 2) = float2{aa, bb};
 }
 
 // y = ca[j] * x + cb[j] for the PER channels from c0 of image b: GroupNorm (mean, rstd from `stat`, or folded here from the few
@@ -381,6 +348,47 @@ __device__ __forceinline__ void gn_channel_coefs(const GNParams& p, const float*
         for (int q = 0; q < PER / 2; ++q) {
             const float4 v = cf[q];                  // a0 b0 a1 b1
             ca[2 * q] = v.x; cb[2 * q] = v.y; ca[2 * q + 1] = v.z; cb[2 * q + 1] = v.w;
+        }
+        return;
+    }
+    if (p.tot0) {
+        // ride-along totals: affine parameters first (independent of the totals, 16-byte loads when aligned), then (mean, rstd) of the
+        // one or two groups these PER channels lie in - one integer division, no f64 division or square root
+        float ga[PER], be[PER], sc[PER], sh[PER];
+        if (p.vec_affine) {
+#pragma unroll
+            for (int q = 0; q < PER / 4; ++q) {
+                const float4 g4 = p.gamma ? reinterpret_cast<const float4*>(p.gamma + c0)[q] : float4{1.f, 1.f, 1.f, 1.f};
+                const float4 b4 = p.beta ? reinterpret_cast<const float4*>(p.beta + c0)[q] : float4{0.f, 0.f, 0.f, 0.f};
+                ga[4 * q] = g4.x; ga[4 * q + 1] = g4.y; ga[4 * q + 2] = g4.z; ga[4 * q + 3] = g4.w;
+                be[4 * q] = b4.x; be[4 * q + 1] = b4.y; be[4 * q + 2] = b4.z; be[4 * q + 3] = b4.w;
+                if (p.scale) {
+                    const float4 s4 = reinterpret_cast<const float4*>(p.scale + (int64_t)b * p.ss_stride + c0)[q];
+                    const float4 h4 = reinterpret_cast<const float4*>(p.shift + (int64_t)b * p.ss_stride + c0)[q];
+                    sc[4 * q] = s4.x; sc[4 * q + 1] = s4.y; sc[4 * q + 2] = s4.z; sc[4 * q + 3] = s4.w;
+                    sh[4 * q] = h4.x; sh[4 * q + 1] = h4.y; sh[4 * q + 2] = h4.z; sh[4 * q + 3] = h4.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                ga[j] = p.gamma ? p.gamma[c0 + j] : 1.f;
+                be[j] = p.beta ? p.beta[c0 + j] : 0.f;
+                if (p.scale) { sc[j] = p.scale[(int64_t)b * p.ss_stride + c0 + j]; sh[j] = p.shift[(int64_t)b * p.ss_stride + c0 + j]; }
+            }
+        }
+        int g = p.div_gs.div(c0);
+        int left = (g + 1) * p.gs - c0;                  // channels of group g from c0 on
+        float mean, rstd;
+        gn_group_from_totals(p, b, g, mean, rstd);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (left == 0) { ++g; left = p.gs; gn_group_from_totals(p, b, g, mean, rstd); }
+            --left;
+            float a = rstd * ga[j];
+            float bb = be[j] - mean * a;
+            if (p.scale) { const float f = 1.f + sc[j]; a *= f; bb = bb * f + sh[j]; }
+            ca[j] = a; cb[j] = bb;
         }
         return;
     }
@@ -427,11 +435,42 @@ __global__ __launch_bounds__(NT) void gn_apply_fast_kernel(const GNParams p, con
     const int tx = tid % p.tpp, pl = tid / p.tpp;
     const int c0 = tx * PER;
     float ca[PER], cb[PER];
-    gn_channel_coefs<PER>(p, stat, b, c0, ca, cb);
     const int pix0 = blockIdx.x * pix_per_blk;
     const int pix1 = min(pix0 + pix_per_blk, p.HW);
     T* outb = reinterpret_cast<T*>(p.out) + (int64_t)b * p.HW * p.C + c0;
     int pix = pix0 + pl;
+    auto act1 = [&](const uint4& vv, int at) {
+        float f[PER];
+        chunk_to_f32<T>(vv, f);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            float y = ca[j] * f[j] + cb[j];
+            if (p.silu) y = (sizeof(T) == 4) ? silu_exact(y) : silu_f(y);
+            f[j] = y;
+        }
+        *reinterpret_cast<uint4*>(outb + (int64_t)at * p.C) = f32_to_chunk<T>(f);
+    };
+    {
+        // the first trip's loads are issued BEFORE the coefficient chain (totals -> group statistics -> a, b: a dependent memory
+        // round trip plus some f64 arithmetic), so that the two latencies overlap - on the small maps a thread has one trip in all
+        const bool full0 = pix + (UNR - 1) * p.ps < pix1;
+        uint4 v0[UNR];
+        if (full0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) v0[u] = load_chunk<T>(p, b, pix + u * p.ps, tx);
+        } else if (pix < pix1) {
+            v0[0] = load_chunk<T>(p, b, pix, tx);
+        }
+        gn_channel_coefs<PER>(p, stat, b, c0, ca, cb);
+        if (full0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) act1(v0[u], pix + u * p.ps);
+            pix += UNR * p.ps;
+        } else if (pix < pix1) {
+            act1(v0[0], pix);
+            pix += p.ps;
+        }
+    }
     for (; pix + (UNR - 1) * p.ps < pix1; pix += UNR * p.ps) {
         uint4 v[UNR];
 #pragma unroll
@@ -532,6 +571,8 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
     p.C0 = C0; p.C1 = C1; p.C = C0 + C1; p.B = B; p.HW = HW; p.G = groups; p.gs = p.C / groups;
     p.nch = p.C / per;
     p.coef = nullptr;
+    p.tot0 = nullptr; p.tot1 = nullptr; p.tg0 = 8; p.tg1 = 8; p.tsh0 = 3; p.tsh1 = 3;
+    p.invN = 1.0 / ((double)HW * p.gs); p.vec_affine = 0; p.div_gs = FastDiv::make(p.gs);
     p.tpp = p.nch < NT ? p.nch : NT;
     p.nslot = cdiv(p.nch, p.tpp);
     p.ps = NT / p.tpp; if (p.ps < 1) p.ps = 1;
@@ -555,16 +596,11 @@ int fill_params(GNParams& p, const void* x0, const void* x1, int C0, int C1, int
         else { using TG = float; __VA_ARGS__; }                          \
     } while (0)
 
-// threads per group of gn_finalize_chunks_kernel: ~4 (chunk, partial) items per thread (each a dependent-latency load), a power of
-// two in [8, 256]
-static int finalize_tpg(int gs, int P0, int P1, int C0, int C1) {
-    const int64_t items = (int64_t)(gs / 4 > 0 ? gs / 4 : 1) * (P0 > P1 ? P0 : P1);
-    (void)C0; (void)C1;
-    int tpg = 8;
-    while (tpg < NT && (int64_t)tpg * 4 < items) tpg *= 2;
-    return tpg;
+static int affine_aligned(const float* gamma, const float* beta, const float* scale, const float* shift, int ss_stride) {
+    const uintptr_t m = reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(scale) |
+                        reinterpret_cast<uintptr_t>(shift);
+    return ((m & 15) == 0 && (ss_stride & 3) == 0) ? 1 : 0;
 }
-#define FIN_GRID(G, B, tpg) dim3(cdiv((G), NT / (tpg)), (B))
 
 // Pixels per apply workgroup: `unit` (= ps x unroll x 4 trips) for the big maps, capped so the grid stays <= GN_APPLY_MAXBLK
 // workgroups; halved down to `ps` (one chunk per thread) while the launch would have fewer than 512 workgroups - the 8x8 ... 32x32
@@ -633,55 +669,50 @@ extern "C" int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int
 
 extern "C" int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B, int HW, int groups, float eps,
                                       const float* gamma, const float* beta, const float* scale, const float* shift,
-                                      int ss_stride, int silu, void* out, void* workspace, int dtype,
-                                      const float* stats0, int P0, int gran0, const float* stats1, int P1, int gran1, void* stream) {
+                                      int ss_stride, int silu, void* out, int dtype,
+                                      const void* stats0, int gran0, const void* stats1, int gran1, void* stream) {
     const int g0 = gran0 == 4 ? 4 : 8, g1 = gran1 == 4 ? 4 : 8;
     NLC_REQUIRE((gran0 == 0 || gran0 == 4 || gran0 == 8) && (gran1 == 0 || gran1 == 4 || gran1 == 8), "nlc_groupnorm_prestats: granules must be 0 (= 8), 4 or 8");
     NLC_REQUIRE(nlc_is16(dtype), "nlc_groupnorm_prestats: bf16 / f16 only (the f32 path computes its statistics itself)");
-    NLC_REQUIRE(x0 && out && workspace && stats0 && P0 > 0, "nlc_groupnorm_prestats: null pointer");
+    NLC_REQUIRE(x0 && out && stats0, "nlc_groupnorm_prestats: null pointer");
     NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm_prestats: bad dims");
-    NLC_REQUIRE((C1 == 0) == (x1 == nullptr) && (C1 == 0) == (stats1 == nullptr) && (C1 == 0 || P1 > 0),
-                "nlc_groupnorm_prestats: x1 / stats1 / C1 mismatch");
+    NLC_REQUIRE((C1 == 0) == (x1 == nullptr) && (C1 == 0) == (stats1 == nullptr), "nlc_groupnorm_prestats: x1 / stats1 / C1 mismatch");
     const int C = C0 + C1;
     NLC_REQUIRE(C % groups == 0 && (C / groups) % g0 == 0 && (C1 == 0 || (C / groups) % g1 == 0) && C0 % 8 == 0 && C1 % 8 == 0,
                 "nlc_groupnorm_prestats: group size %d must be a multiple of the statistics granules (%d, %d) and C0=%d, C1=%d of 8", C / groups, g0, g1, C0, C1);
     NLC_REQUIRE(C / 8 <= NT, "nlc_groupnorm_prestats: C=%d too large for the one-chunk-per-thread apply kernel", C);
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_prestats: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_prestats: ss_stride < C");
+    NLC_REQUIRE(((reinterpret_cast<uintptr_t>(stats0) | reinterpret_cast<uintptr_t>(stats1)) & 15) == 0, "nlc_groupnorm_prestats: statistics must be 16-byte aligned");
     GNParams p;
     fill_params(p, x0, x1, C0, C1, B, HW, groups, dtype);
     p.eps = eps; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
-    p.silu = silu; p.out = (char*)out; p.ws = (double*)workspace;
-    hipStream_t st = (hipStream_t)stream;
-    float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
+    p.silu = silu; p.out = (char*)out; p.ws = nullptr;
+    p.tot0 = (const long long*)stats0; p.tot1 = (const long long*)stats1; p.tg0 = g0; p.tg1 = g1;
+    p.tsh0 = g0 == 4 ? 2 : 3; p.tsh1 = g1 == 4 ? 2 : 3;
+    p.vec_affine = affine_aligned(gamma, beta, scale, shift, ss_stride);
     const int ppb = apply_pix_per_block(HW, B, p.ps, p.ps * UNR * 4);
-    // the finalize kernel also folds gamma / beta / FiLM into one (a, b) pair per (image, channel): the apply threads then start
-    // with four 16-byte loads instead of five scalar loads and the algebra per channel
-    float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
-    const int tpg = finalize_tpg(p.gs, P0, P1, C0, C1);
-    hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C0, stats1, P1, C1, p.gs, groups, HW,
-                       eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, g1);
-    p.coef = coef;
-    NLC_SWITCH_16(dtype, hipLaunchKernelGGL(gn_apply_fast_kernel<T16>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, st, p, stat, ppb));
+    // ONE launch: every apply thread derives its channels' (a, b) from the totals (gn_group_from_totals)
+    NLC_SWITCH_16(dtype, hipLaunchKernelGGL(gn_apply_fast_kernel<T16>, dim3(cdiv(HW, ppb), B), dim3(NT), 0, (hipStream_t)stream, p, (const float*)nullptr, ppb));
     NLC_CHECK_LAUNCH("nlc_groupnorm_prestats");
     return NLC_OK;
 }
 
 extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, int groups, float eps, const float* gamma,
                                      const float* beta, const float* scale, const float* shift, int ss_stride, int silu,
-                                     void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0, int gran0,
+                                     void* out_norm, void* out_x, void* workspace, int dtype, const void* stats0, int gran0,
                                      void* stream) {
     const int g0 = gran0 == 4 ? 4 : 8;
     NLC_REQUIRE(gran0 == 0 || gran0 == 4 || gran0 == 8, "nlc_groupnorm_pool2x2: granule must be 0 (= 8), 4 or 8");
     NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_groupnorm_pool2x2: bad dtype %d", dtype);
     const int per = nlc_is16(dtype) ? 8 : 4;
-    NLC_REQUIRE(x && out_norm && out_x && workspace, "nlc_groupnorm_pool2x2: null pointer");
+    NLC_REQUIRE(x && out_norm && out_x && (workspace || stats0), "nlc_groupnorm_pool2x2: null pointer");
     NLC_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && groups > 0 && H % 2 == 0 && W % 2 == 0, "nlc_groupnorm_pool2x2: bad dims (H, W even)");
     NLC_REQUIRE(C % per == 0 && C % groups == 0, "nlc_groupnorm_pool2x2: C=%d must be a multiple of %d and of groups=%d", C, per, groups);
     NLC_REQUIRE(C / per <= NT, "nlc_groupnorm_pool2x2: C=%d too large for the one-chunk-per-thread kernels", C);
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_pool2x2: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_pool2x2: ss_stride < C");
-    NLC_REQUIRE(!stats0 || (nlc_is16(dtype) && P0 > 0 && (C / groups) % g0 == 0),
+    NLC_REQUIRE(!stats0 || (nlc_is16(dtype) && (C / groups) % g0 == 0 && (reinterpret_cast<uintptr_t>(stats0) & 15) == 0),
                 "nlc_groupnorm_pool2x2: ride-along statistics are bf16 / f16 only, group size a multiple of their granule");
     const int HW = H * W;
     GNParams p;
@@ -689,14 +720,12 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
     p.eps = eps; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
     p.silu = silu; p.out = (char*)out_norm; p.ws = (double*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    float* stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
+    float* stat = nullptr;
     if (stats0) {
-        float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(stat + (int64_t)B * groups * 2) + 15) & ~uintptr_t(15));
-        const int tpg = finalize_tpg(p.gs, P0, 0, C, 0);
-        hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, st, stats0, P0, C, (const float*)nullptr, 0, 0, p.gs,
-                           groups, HW, eps, stat, GNCoefOut{coef, gamma, beta, scale, shift, ss_stride}, tpg, g0, 8);
-        p.coef = coef;
+        p.tot0 = (const long long*)stats0; p.tg0 = g0; p.tsh0 = g0 == 4 ? 2 : 3;   // the apply threads derive (a, b) from the totals: no other launch
+        p.vec_affine = affine_aligned(gamma, beta, scale, shift, ss_stride);
     } else {
+        stat = reinterpret_cast<float*>(p.ws + (int64_t)B * MAX_NBLK * groups * 3);
         const size_t lds_stats = (size_t)p.ps * p.C * 3 * sizeof(float);
         NLC_REQUIRE(lds_stats <= 64 * 1024, "nlc_groupnorm_pool2x2: LDS budget exceeded (C=%d)", C);
         GN_SWITCH(dtype, hipLaunchKernelGGL(gn_stats_fast_kernel<TG>, dim3(p.nblk, B), dim3(NT), lds_stats, st, p));
@@ -711,21 +740,25 @@ extern "C" int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, 
 }
 
 extern "C" int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
-                                  const float* scale, const float* shift, int ss_stride, const float* stats0, int P0, int gran0,
-                                  const float* stats1, int P1, int gran1, float* coef, void* stream) {
+                                  const float* scale, const float* shift, int ss_stride, const void* stats0, int gran0,
+                                  const void* stats1, int gran1, float* coef, void* stream) {
     const int g0 = gran0 == 4 ? 4 : 8, g1 = gran1 == 4 ? 4 : 8;
-    NLC_REQUIRE(coef && stats0 && P0 > 0, "nlc_groupnorm_coef: null pointer");
+    NLC_REQUIRE(coef && stats0, "nlc_groupnorm_coef: null pointer");
     NLC_REQUIRE(B > 0 && HW > 0 && C0 > 0 && C1 >= 0 && groups > 0, "nlc_groupnorm_coef: bad dims");
-    NLC_REQUIRE((C1 == 0) == (stats1 == nullptr) && (C1 == 0 || P1 > 0), "nlc_groupnorm_coef: stats1 / C1 mismatch");
+    NLC_REQUIRE((C1 == 0) == (stats1 == nullptr), "nlc_groupnorm_coef: stats1 / C1 mismatch");
     const int C = C0 + C1;
     NLC_REQUIRE(C % groups == 0 && (C / groups) % g0 == 0 && (C1 == 0 || (C / groups) % g1 == 0) && C0 % 8 == 0 && C1 % 8 == 0,
                 "nlc_groupnorm_coef: group size %d must be a multiple of the statistics granules and C0=%d, C1=%d of 8", C / groups, C0, C1);
     NLC_REQUIRE((scale == nullptr) == (shift == nullptr), "nlc_groupnorm_coef: scale/shift must come together");
     NLC_REQUIRE(!scale || ss_stride >= C, "nlc_groupnorm_coef: ss_stride < C");
-    GNCoefOut co{coef, gamma, beta, scale, shift, ss_stride};
-    const int tpg = finalize_tpg(C / groups, P0, P1, C0, C1);
-    hipLaunchKernelGGL(gn_finalize_chunks_kernel, FIN_GRID(groups, B, tpg), dim3(NT), 0, (hipStream_t)stream, stats0, P0, C0, stats1, P1, C1,
-                       C / groups, groups, HW, eps, (float*)nullptr, co, tpg, g0, g1);
+    NLC_REQUIRE(((reinterpret_cast<uintptr_t>(stats0) | reinterpret_cast<uintptr_t>(stats1)) & 15) == 0, "nlc_groupnorm_coef: statistics must be 16-byte aligned");
+    GNParams p{};
+    p.C0 = C0; p.C1 = C1; p.C = C; p.B = B; p.HW = HW; p.G = groups; p.gs = C / groups; p.eps = eps;
+    p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
+    p.tot0 = (const long long*)stats0; p.tot1 = (const long long*)stats1; p.tg0 = g0; p.tg1 = g1;
+    p.tsh0 = g0 == 4 ? 2 : 3; p.tsh1 = g1 == 4 ? 2 : 3;
+    p.invN = 1.0 / ((double)HW * p.gs); p.div_gs = FastDiv::make(p.gs);
+    hipLaunchKernelGGL(gn_coef_from_totals_kernel, dim3(cdiv(C, NT), B), dim3(NT), 0, (hipStream_t)stream, p, coef);
     NLC_CHECK_LAUNCH("nlc_groupnorm_coef");
     return NLC_OK;
 }

@@ -324,7 +324,7 @@ class ExperimentDiffusion:
     def denoise_loop(self, shape, gen=None, norm_init_noise=False, style="base", constrain_fn=None, norm_eps=False,
                      refine_prior_sigma=False, xT=None, return_log=True, chunk_size=2, sigma_pred_threshold=1000,
                      new_eta=None, constrain_loss=None, return_best=True, free_const_steps=-1, noise_list=None,
-                     return_on_device=False, max_steps=None):
+                     return_on_device=False, max_steps=None, start_step=0):
         """src/experiments.py:329-397.  ``noise_list`` (optional) supplies the per-step N(0,1) draws that
         stochastic samplers consume; by default they come from the global CPU generator, one
         ``randn(shape)`` per step, in step order.  ``return_on_device`` keeps the returned sample in HBM (the
@@ -332,7 +332,9 @@ class ExperimentDiffusion:
         that many timesteps of the schedule (parity checks against a partial oracle trajectory); with ``return_log`` the
         NLC-corrected per-sample sigma_t of every timestep is kept in ``self.sigma_trace`` (a list of CPU [B] tensors) and the
         state x_t every timestep STARTED from in ``self.xt_trace`` (CPU; teacher-forced per-timestep comparisons of two
-        precisions feed one run's x_t to the other's ``get_denoise_vector``)."""
+        precisions feed one run's x_t to the other's ``get_denoise_vector``).  ``start_step`` = k resumes the schedule at its
+        k-th timestep from ``xT`` = the state that timestep starts from (a run whose first k timesteps were made in another
+        precision: tools/parity_trace.py --mixed)."""
         S = self.scheduler
         S.reset_state()
         dev = self.device
@@ -365,6 +367,9 @@ class ExperimentDiffusion:
             x0_before = x0
         self.sigma_trace, self.xt_trace = [], []
         for ind, (t, t_prev) in enumerate(pairwise(ts_host.tolist())):
+            if ind < start_step:
+                S.i += 1
+                continue
             if max_steps is not None and ind >= max_steps:
                 break
             if return_log:

@@ -71,7 +71,7 @@ def _graphable(fn):
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
         if not self.use_graphs or torch.cuda.is_current_stream_capturing():
-            return fn(self, *args, **kwargs)
+            return self._eval(fn, args, kwargs)
         return self._graph_call(fn, args, kwargs)
     return wrapper
 
@@ -87,13 +87,24 @@ class HipModule:
             if name in cls.__dict__:
                 setattr(cls, name, _graphable(cls.__dict__[name]))
 
+    def _eval(self, fn, args, kwargs):
+        """One network evaluation: the ride-along GroupNorm statistics of all its convolutions are slices of this module's arena,
+        zeroed by one memset up front (ops.StatsArena)."""
+        if self.device.type != "cuda":
+            return fn(self, *args, **kwargs)
+        arena = self.__dict__.get("_stats_arena")
+        if arena is None:
+            arena = self.__dict__["_stats_arena"] = ops.StatsArena()
+        with ops.stats_scope(arena, self.device):
+            return fn(self, *args, **kwargs)
+
     def _graph_call(self, fn, args, kwargs):
         self._require_gpu()
         items = list(args) + [kwargs[k] for k in sorted(kwargs)]
         # (an input that carries ride-along GroupNorm statistics - ops.conv2d attaches them to its output - keeps them through the
         #  static copy: the captured network must consume the same statistics an eager call would, not recompute them in another
         #  summation order)
-        stats_of = lambda a: getattr(a, "_nlc_stats", None) if torch.is_tensor(a) else None
+        stats_of = lambda a: ops.ride_stats(a) if torch.is_tensor(a) else None
         key = (fn.__name__, self.compute_dtype, self.matmul, ops.config_key(), len(args), tuple(sorted(kwargs)),
                tuple((tuple(a.shape), a.dtype, None if stats_of(a) is None else tuple(stats_of(a).shape)) if torch.is_tensor(a) else a
                      for a in items))
@@ -117,11 +128,13 @@ class HipModule:
                 s_kwargs = dict(zip(sorted(kwargs), static[len(args):]))
                 cs.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(cs):
-                    fn(self, *s_args, **s_kwargs)
+                    self._eval(fn, s_args, s_kwargs)
+                    if self.__dict__["_stats_arena"].overflowed:       # first evaluation ever: the arena is sized now, so that the
+                        self._eval(fn, s_args, s_kwargs)              # capture below only zeroes it (no allocation inside the graph)
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=cs):
-                    out = fn(self, *s_args, **s_kwargs)
+                    out = self._eval(fn, s_args, s_kwargs)
                 ent = cache[key] = (g, static, out)
             g, static, out = ent
             for a, st in zip(items, static):

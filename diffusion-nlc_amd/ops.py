@@ -165,7 +165,95 @@ def stats_granule(cout: int, groups_hint: int = 32) -> int:
 
 
 def _stats_gran_of(t: torch.Tensor, st: torch.Tensor) -> int:
-    return t.shape[-1] // st.shape[2]
+    return t.shape[-1] // st.shape[1]
+
+
+# ---- ride-along GroupNorm statistics: zeroed accumulators ---------------------------------------------------------------------
+# A convolution ADDS the (sum, sum of squares) totals of its output to an int64 [B, C/g, 4] buffer that must be zero when it starts
+# (include/nlc_hip.h, nlc_conv_desc.stats_out).  Inside a network evaluation the buffers of all its convolutions are slices of ONE
+# arena that is zeroed by ONE memset when the evaluation begins (HipModule wraps run / run_nhwc in stats_scope); outside of one
+# (tests, tools calling conv2d directly) every call gets a zeroed tensor of its own.
+class StatsArena:
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.off = 0
+        self.need = 0              # int64 elements the last evaluation asked for
+        self.gen = 0               # evaluations begun: a statistics slice is valid only within the evaluation that produced it
+        self.overflowed = False
+        self.retired = []          # outgrown buffers stay allocated: hipGraphs captured earlier hold their addresses
+
+    def begin(self, device) -> None:
+        want = max(self.need, 1 << 16)
+        if self.buf is None or self.buf.device != torch.device(device) or self.buf.numel() < self.need:
+            if self.buf is not None:
+                self.retired.append(self.buf)
+            self.buf = torch.zeros(want + want // 4, device=device, dtype=torch.int64)
+        else:
+            self.buf.zero_()
+        self.off, self.need, self.overflowed = 0, 0, False
+        self.gen += 1
+
+    def alloc(self, n: int, device) -> torch.Tensor:
+        n = (n + 1) & ~1                                    # 16-byte aligned slices
+        self.need += n
+        if self.buf is not None and self.off + n <= self.buf.numel():
+            v = self.buf[self.off:self.off + n]
+            self.off += n
+            return v
+        self.overflowed = True                              # this evaluation: a memset of its own; the arena grows at the next begin()
+        return torch.zeros(n, device=device, dtype=torch.int64)
+
+
+_ARENA: Optional[StatsArena] = None
+
+
+class stats_scope:
+    """``with stats_scope(arena, device):`` - the statistics buffers of every conv2d / conv_first inside come from ``arena``."""
+
+    def __init__(self, arena: StatsArena, device):
+        self.arena, self.device = arena, device
+
+    def __enter__(self):
+        global _ARENA
+        self.prev = _ARENA
+        self.arena.begin(self.device)
+        _ARENA = self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = self.prev
+        return False
+
+
+def _new_stats(out: torch.Tensor, B: int, cout: int, gran: int) -> torch.Tensor:
+    """A zeroed int64 [B, cout/gran, 4] totals buffer attached to ``out`` (consumed by groupnorm(); lives and dies with the tensor
+    object, and - when it is a slice of an evaluation's arena - is only honoured within that evaluation: ride_stats())."""
+    n = B * (cout // gran) * 4
+    if _ARENA is not None:
+        st = _ARENA.alloc(n, out.device).view(B, cout // gran, 4)
+        if not torch.cuda.is_current_stream_capturing():
+            # (inside a capture the tensor is a static output of the graph: valid until the next replay that writes the same
+            #  arena - the documented contract of HipModule's graph mode - and Python-side generations do not advance on replay)
+            out._nlc_stats_gen = (_ARENA, _ARENA.gen)
+    else:
+        st = torch.zeros(B, cout // gran, 4, device=out.device, dtype=torch.int64)
+    out._nlc_stats = st
+    return st
+
+
+def ride_stats(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The totals that rode along with the convolution that produced ``t``, or None (none attached, or their arena has been
+    re-zeroed by a later evaluation: the consumer then computes the statistics itself)."""
+    if t is None:
+        return None
+    st = getattr(t, "_nlc_stats", None)
+    if st is None:
+        return None
+    tag = getattr(t, "_nlc_stats_gen", None)
+    if tag is not None and tag[0].gen != tag[1]:
+        return None
+    return st
 
 
 def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = None, stride: int = 1,
@@ -240,14 +328,12 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         if gn_coef.dtype != torch.float32 or not gn_coef.is_cuda or gn_coef.numel() < B * pw.Cin * 2 + 128:
             raise ValueError("conv2d: gn_coef must be a CUDA f32 [B, Cin, 2] table with >= 512 bytes of slack (groupnorm_coef)")
         d.gn_coef, d.gn_act = gn_coef.data_ptr(), gn_act
-    stats = None
     if is16(dt) and emit_stats and not out_nchw_f32 and not linear:
-        # GroupNorm statistics of the output ride along in the epilogue when this launch takes the LDS-halo kernel
-        P = lib.nlc_conv2d_stats_partials(C.byref(d), dtype_enum(dt))
-        if P > 0:
+        # GroupNorm statistics of the output ride along in the epilogue (totals, added atomically into a zeroed buffer)
+        if lib.nlc_conv2d_stats_partials(C.byref(d), dtype_enum(dt)) > 0:
             gran = stats_granule(pw.Cout)
-            stats = torch.empty(B, P, pw.Cout // gran, 2, device=x0.device, dtype=torch.float32)
-            d.stats_out, d.stats_bytes, d.stats_granule = stats.data_ptr(), stats.numel() * 4, gran
+            stats = _new_stats(out, B, pw.Cout, gran)
+            d.stats_out, d.stats_bytes, d.stats_granule = stats.data_ptr(), stats.numel() * 8, gran
     if is16(dt) or allow_split:      # split-K scratch for the few-tile / long-K levels (a cheap host query)
         need = lib.nlc_conv2d_workspace_bytes(C.byref(d), dtype_enum(dt))
         if need > 0:
@@ -266,8 +352,6 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         _launch_conv(lib, d, dt)
     if linear and not out_nchw_f32:
         out = out.view(B, pw.Cout)
-    if stats is not None:
-        out._nlc_stats = stats                  # consumed by groupnorm(); lives and dies with this tensor object
     return out
 
 
@@ -275,10 +359,11 @@ def _launch_conv(lib, d: ConvDesc, dt: torch.dtype) -> None:
     try:
         check(lib.nlc_conv2d(C.byref(d), dtype_enum(dt), _stream()), "nlc_conv2d")
     except _ext.NlcError as e:
-        if d.workspace and e.rc == _ext.NLC_ELAUNCH:
-            # a split-K launch that did not complete may leave arrival counters non-zero, and every later split launch on this
-            # workspace would then reduce early or never: drop the workspace, the next call allocates a zeroed one.  (A call the
-            # library REJECTED - NLC_EINVAL / NLC_EUNSUPPORTED - launched nothing and leaves the workspace as it was.)
+        if d.workspace and (e.rc == _ext.NLC_ELAUNCH or "poisoned workspace" in str(e)):
+            # a split-K launch that did not complete may leave arrival counters non-zero (and the debug check of desc.debug bit 0
+            # has just found some), and every later split launch on this workspace would then reduce early or never: drop the
+            # workspace, the next call allocates a zeroed one.  (Any other call the library REJECTED - NLC_EINVAL /
+            # NLC_EUNSUPPORTED - launched nothing and leaves the workspace as it was.)
             reset_conv_workspaces()
         raise
 
@@ -315,15 +400,12 @@ def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
         raise ValueError("conv_first: weight shape mismatch")
     out = torch.empty(B, H, W, Cout, device=x_nchw.device, dtype=dtype)
     stats = None
-    P = lib.nlc_conv_first_stats_partials(Cin, H, W, Cout, k, k, dtype_enum(dtype))
     gran = stats_granule(Cout)
-    if P > 0:
-        stats = torch.empty(B, P, Cout // gran, 2, device=x_nchw.device, dtype=torch.float32)
+    if lib.nlc_conv_first_stats_partials(Cin, H, W, Cout, k, k, dtype_enum(dtype)) > 0:
+        stats = _new_stats(out, B, Cout, gran)
     check(lib.nlc_conv_first(x_nchw.data_ptr(), _ptr(in_scale), w.data_ptr(), _ptr(bias), out.data_ptr(),
                              B, Cin, H, W, Cout, k, k, dtype_enum(dtype), _ptr(stats),
-                             0 if stats is None else stats.numel() * 4, gran, _stream()), "nlc_conv_first")
-    if stats is not None:
-        out._nlc_stats = stats
+                             0 if stats is None else stats.numel() * 8, gran, _stream()), "nlc_conv_first")
     return out
 
 
@@ -392,20 +474,19 @@ def groupnorm(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[to
         ss_stride = scale.stride(0)
         if shift.stride(0) != ss_stride:
             raise ValueError("groupnorm: scale/shift must share a row stride")
-    ws = _gn_workspace(x0.device, lib.nlc_groupnorm_workspace_bytes(B, HW, Ctot, groups))
     if FUSED_GN_STATS and is16(dt) and Ctot % groups == 0 and C0 % 8 == 0 and C1 % 8 == 0 and Ctot // 8 <= 256:
-        s0 = getattr(x0, "_nlc_stats", None)
-        s1 = getattr(x1, "_nlc_stats", None) if x1 is not None else None
+        s0 = ride_stats(x0)
+        s1 = ride_stats(x1)
         gs = Ctot // groups
         g0 = _stats_gran_of(x0, s0) if s0 is not None else 8
         g1 = _stats_gran_of(x1, s1) if s1 is not None else 8
         if s0 is not None and (x1 is None or s1 is not None) and gs % g0 == 0 and (x1 is None or gs % g1 == 0):
-            # statistics came with the producing convolutions: finalize from their chunk sums + apply (2 passes, not 3)
+            # the totals came with the producing convolutions: ONE streaming launch (its threads derive their coefficients)
             check(lib.nlc_groupnorm_prestats(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
                                              _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(),
-                                             ws.data_ptr(), dtype_enum(dt), s0.data_ptr(), s0.shape[1], g0, _ptr(s1),
-                                             0 if s1 is None else s1.shape[1], g1, _stream()), "nlc_groupnorm_prestats")
+                                             dtype_enum(dt), s0.data_ptr(), g0, _ptr(s1), g1, _stream()), "nlc_groupnorm_prestats")
             return out
+    ws = _gn_workspace(x0.device, lib.nlc_groupnorm_workspace_bytes(B, HW, Ctot, groups))
     check(lib.nlc_groupnorm(x0.data_ptr(), _ptr(x1), C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta),
                             _ptr(scale), _ptr(shift), ss_stride, 1 if silu else 0, out.data_ptr(), ws.data_ptr(),
                             dtype_enum(dt), _stream()), "nlc_groupnorm")
@@ -435,14 +516,14 @@ def groupnorm_pool2x2(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Opti
     ws = _gn_workspace(x.device, lib.nlc_groupnorm_workspace_bytes(B, H * W, Cc, groups))
     s0, g0 = None, 8
     if FUSED_GN_STATS and is16(dt) and Cc % groups == 0:
-        s0 = getattr(x, "_nlc_stats", None)
+        s0 = ride_stats(x)
         if s0 is not None:
             g0 = _stats_gran_of(x, s0)
             if (Cc // groups) % g0:
                 s0 = None
     check(lib.nlc_groupnorm_pool2x2(x.data_ptr(), Cc, B, H, W, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift),
                                     ss_stride, 1 if silu else 0, out_h.data_ptr(), out_x.data_ptr(), ws.data_ptr(), dtype_enum(dt),
-                                    _ptr(s0), 0 if s0 is None else s0.shape[1], g0, _stream()), "nlc_groupnorm_pool2x2")
+                                    _ptr(s0), g0, _stream()), "nlc_groupnorm_pool2x2")
     return out_h, out_x
 
 
@@ -474,8 +555,8 @@ def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1
     Ctot = C0 + C1
     if C0 % 8 or C1 % 8 or Ctot % groups:
         return None
-    s0 = getattr(x0, "_nlc_stats", None)
-    s1 = getattr(x1, "_nlc_stats", None) if x1 is not None else None
+    s0 = ride_stats(x0)
+    s1 = ride_stats(x1)
     if s0 is None or (x1 is not None and s1 is None):
         return None
     g0 = _stats_gran_of(x0, s0)
@@ -490,8 +571,7 @@ def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1
             raise ValueError("groupnorm_coef: scale/shift must be row-strided f32 views sharing a row stride")
     coef = torch.empty(B * Ctot * 2 + 128, device=x0.device, dtype=torch.float32)        # + 512 bytes: the consumer's DMA reads whole 1-KiB pieces
     check(lib.nlc_groupnorm_coef(C0, C1, B, HW, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), ss_stride,
-                                 s0.data_ptr(), s0.shape[1], g0, _ptr(s1), 0 if s1 is None else s1.shape[1], g1, coef.data_ptr(),
-                                 _stream()), "nlc_groupnorm_coef")
+                                 s0.data_ptr(), g0, _ptr(s1), g1, coef.data_ptr(), _stream()), "nlc_groupnorm_coef")
     return coef
 
 

@@ -144,11 +144,16 @@ typedef struct nlc_conv_desc {
     int64_t workspace_bytes; /* K (the 8x8 / 16x16 levels); size from nlc_conv2d_workspace_bytes.  Its FIRST 4096 BYTES are    */
                          /* the library's arrival counters: zero them once when the buffer is allocated and never write them; */
                          /* every launch leaves them zero.  The rest is undefined scratch.  One workspace per stream.          */
-    void* stats_out;     /* optional (NULL = none): GroupNorm statistics of the output, written by the conv's epilogue so    */
-    int64_t stats_bytes; /* that the normalisation that follows (src/unet_adm.py:182-184,206-208) skips its statistics pass: */
-                         /* float [B][P][Cout/8][2] = (sum, sum of squares) of the STORED values per 8-channel chunk and     */
-                         /* partial; P = nlc_conv2d_stats_partials(desc, dtype) must be > 0 (bf16, NHWC, Cout % 128 == 0,    */
-                         /* launches that take the LDS-halo kernel).  Consumed by nlc_groupnorm_prestats.                    */
+    void* stats_out;     /* optional (NULL = none): GroupNorm statistics of the output ride along in the conv's epilogue so   */
+    int64_t stats_bytes; /* that the normalisation that follows (src/unet_adm.py:182-184,206-208) needs NO pass over the     */
+                         /* tensor, no reduction and no finalize launch: int64 [B][Cout/g][4] = per g-channel chunk the TOTALS */
+                         /* (sum.hi, sum.lo, sumsq.hi, sumsq.lo) of the STORED (rounded) values, g = stats_granule.  Every      */
+                         /* workgroup ADDS its contributions with 64-bit integer atomics - a contribution v (an f32 partial    */
+                         /* sum) as hi = floor(v), lo = floor((v - hi) 2^44); value = hi + lo 2^-44 - so the totals are exact   */
+                         /* sums of the contributions in ANY arrival order: bit-reproducible.  The CALLER ZEROES the buffer    */
+                         /* before the launch (the library only adds); 16-byte aligned.  nlc_conv2d_stats_partials(desc,      */
+                         /* dtype) must be > 0 (16-bit, NHWC, Cout % 128 == 0, the LDS-halo and LDS-DMA kernels).  Consumed by */
+                         /* nlc_groupnorm_prestats / _pool2x2 / _coef.                                                        */
     int32_t policy;      /* NLC_CONV_* (0 = AUTO); the three queries below honour it like nlc_conv2d does */
     const float* gn_coef; /* optional (NULL = none): the GroupNorm (+FiLM) (+SiLU) that precedes this convolution in the reference */
     int32_t gn_act;      /* (src/unet_adm.py:182-185,206-211,248-252) applied to the INPUT on its way through LDS instead of in a     */
@@ -162,7 +167,7 @@ typedef struct nlc_conv_desc {
                          /* skip branch x_upd(x) of an up-sampling ResBlock (src/unet_adm.py:186-190, nearest-2x Upsample) read    */
                          /* in place of a materialised upsampled copy.  Hout, Wout must be even.                                  */
     int32_t stats_granule; /* channels per chunk of stats_out: 0 or 8 = per 8 channels, 4 = per 4 (for a GroupNorm whose groups are 4 or 12 ...  */
-                         /* channels wide: 128 channels in 32 groups); stats_out is then float [B][P][Cout/4][2].                       */
+                         /* channels wide: 128 channels in 32 groups); stats_out is then int64 [B][Cout/4][4].                          */
     int32_t math;        /* NLC_MATH_* (0 = the dtype's native MFMA).  NLC_MATH_F16X3 needs dtype NLC_F32 and `w` packed by          */
                          /* nlc_pack_conv_weights_ex(..., NLC_MATH_F16X3): the packed tensor then holds (hi, lo) f16 halves of every  */
                          /* weight in the k order the kernels read, same byte size as the f32 packing.                                 */
@@ -180,7 +185,7 @@ int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
  * is the caller's opt-in: with none, one summation order is kept (the f32 parity path).  Partial sums are f32 and are
  * added in a fixed order. */
 int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype);
-/* partials per image (P) with which nlc_conv2d would fill stats_out for this descriptor; 0: it would not emit statistics */
+/* 1 if nlc_conv2d would add this launch's GroupNorm statistics to stats_out for this descriptor, 0: it would not */
 int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype);
 /* 1 if nlc_conv2d would apply desc.gn_coef / gn_act in its LDS prologue for this descriptor (geometry, dtype and policy decide;
  * the gn_* fields themselves are not looked at), else 0: the caller then runs nlc_groupnorm(_prestats) as a separate pass */
@@ -195,9 +200,9 @@ int nlc_conv_first(const float* x_nchw, const float* in_scale /*[B] or NULL*/,
                    const float* w, const float* bias, void* out_nhwc,
                    int B, int Cin, int H, int W, int Cout, int KH, int KW,
                    int dtype, void* stats_out /* or NULL */, int64_t stats_bytes, int stats_granule /* 0 | 8 | 4 */, void* stream);
-/* stats_out: GroupNorm statistics of the output, float [B][P][Cout/granule][2] as in nlc_conv_desc.stats_out, with
- * P = nlc_conv_first_stats_partials(...) > 0 (bf16, KH*KW*Cin <= 32, Cout <= 256 and a multiple of 16, H*W a
- * multiple of 64: the launches that take the matrix-core kernel). */
+/* stats_out: GroupNorm statistics of the output, int64 [B][Cout/granule][4] totals as in nlc_conv_desc.stats_out (zeroed by the
+ * caller, added to by the kernel), when nlc_conv_first_stats_partials(...) > 0 (16-bit, KH*KW*Cin <= 32, Cout <= 256 and a
+ * multiple of 16, H*W a multiple of 64: the launches that take the matrix-core kernel). */
 int nlc_conv_first_stats_partials(int Cin, int H, int W, int Cout, int KH, int KW, int dtype);
 
 /* ------------------------------------------------------------------------------------
@@ -214,34 +219,36 @@ int nlc_groupnorm(const void* x0, const void* x1, int C0, int C1, int B, int HW,
                   const float* scale, const float* shift, int ss_stride,
                   int silu, void* out, void* workspace, int dtype, void* stream);
 /* Same, but the statistics come from the producing convolutions' epilogues (nlc_conv_desc.stats_out) instead of a pass
- * over the input: stats0 / stats1 = float [B][P0|P1][C0/8 | C1/8][2] for x0 / x1.  Requires bf16, (C0+C1)/groups a
- * multiple of 8 and C0 a multiple of 8 (a group may straddle the two sources).  Partials are added in a fixed order
- * in f64; var = E[x^2] - E[x]^2 there. */
+ * over the input: stats0 / stats1 = the int64 [B][C0/g0 | C1/g1][4] totals of x0 / x1.  ONE launch: every thread of the
+ * streaming kernel derives its channels' coefficients from the totals of the one or two groups they lie in (f64:
+ * var = E[x^2] - E[x]^2).  Requires a 16-bit dtype, (C0+C1)/groups a multiple of both granules and C0, C1 multiples of 8 (a
+ * group may straddle the two sources).  No workspace. */
 int nlc_groupnorm_prestats(const void* x0, const void* x1, int C0, int C1, int B, int HW,
                            int groups, float eps, const float* gamma, const float* beta,
                            const float* scale, const float* shift, int ss_stride,
-                           int silu, void* out, void* workspace, int dtype,
-                           const float* stats0, int P0, int granule0, const float* stats1, int P1, int granule1, void* stream);
+                           int silu, void* out, int dtype,
+                           const void* stats0, int granule0, const void* stats1, int granule1, void* stream);
 /* granule0 / granule1: channels per chunk of stats0 / stats1 (0 or 8, or 4 - nlc_conv_desc.stats_granule of the producer); the
  * group size must be a multiple of both. */
 
 /* The two branches of a down-sampling ResBlock from ONE read of x (src/unet_adm.py:193-195: h = in_rest(x); h = h_upd(h);
  * x = x_upd(x), both AvgPool2d(2)):  out_norm = avgpool2x2(act(GroupNorm(x) (FiLM))),  out_x = avgpool2x2(x), both
- * [B][H/2][W/2][C]; the full-resolution normalised tensor is never written.  Statistics: stats0 / P0 as in
- * nlc_groupnorm_prestats (bf16), or NULL / 0 -> computed here by a pass over x.  f32: bit-identical to nlc_groupnorm followed by
- * nlc_avgpool2x2; bf16: the pooled mean is taken of the f32 activations (one rounding less).  Same workspace as nlc_groupnorm. */
+ * [B][H/2][W/2][C]; the full-resolution normalised tensor is never written.  Statistics: stats0 as in
+ * nlc_groupnorm_prestats (16-bit), or NULL -> computed here by a pass over x.  f32: bit-identical to nlc_groupnorm followed by
+ * nlc_avgpool2x2; 16-bit: the pooled mean is taken of the f32 activations (one rounding less).  Same workspace as nlc_groupnorm
+ * (may be NULL when stats0 is given). */
 int nlc_groupnorm_pool2x2(const void* x, int C, int B, int H, int W, int groups, float eps, const float* gamma,
                           const float* beta, const float* scale, const float* shift, int ss_stride, int silu,
-                          void* out_norm, void* out_x, void* workspace, int dtype, const float* stats0, int P0, int granule0,
+                          void* out_norm, void* out_x, void* workspace, int dtype, const void* stats0, int granule0,
                           void* stream);
 
 /* The per-(image, channel) coefficients of the same normalisation, for the convolution that applies it in its LDS prologue
  * (nlc_conv_desc.gn_coef): coef[b][c] = (a, b) with  a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift,
- * statistics from the producing convolutions' epilogues exactly as in nlc_groupnorm_prestats (same f64 fixed-order fold).
+ * statistics from the producing convolutions' epilogues exactly as in nlc_groupnorm_prestats (same f64 arithmetic on the totals).
  * coef: float [B][C0+C1][2] (+ >= 512 bytes of slack behind it for the consumer's DMA). */
 int nlc_groupnorm_coef(int C0, int C1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
-                       const float* scale, const float* shift, int ss_stride, const float* stats0, int P0, int granule0,
-                       const float* stats1, int P1, int granule1, float* coef, void* stream);
+                       const float* scale, const float* shift, int ss_stride, const void* stats0, int granule0,
+                       const void* stats1, int granule1, float* coef, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-head softmax attention on token-major tensors (flash style, no TxT matrix in HBM).

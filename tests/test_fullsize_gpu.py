@@ -135,16 +135,22 @@ def test_adm256_f32_ten_steps_match_the_oracle_at_full_size(adm256, adm256_oracl
 # sigma_0 = 100 turns a relative error d of the corrected sigma into ~100 d |eps| of x0, and the sampling map expands errors ~x1.13
 # per timestep), so their gates are TOLERANCES on quantities that stay comparable, measured against the HIP f32x3 path - which the
 # test above pins to the CPU oracle on the same schedule:
-#   (1) teacher-forced, per timestep: from the f32x3 run's own state x_t at timesteps TF_STEPS of the 50, one 16-bit NLC step; the
-#       corrected sigma (what NLC is for) within SIGMA_TOL relative for every image, the eps prediction within EPS_TOL relative RMS;
-#   (2) free-running, all 50 timesteps, B = 16, same x_T: per-image mean and standard deviation of the final sample within
-#       MEAN_TOL / STD_TOL of the f32x3 sample's, and the 16-bit sample closer (RMS) to the f32x3 sample of the SAME seed than any
-#       two f32x3 samples of different seeds are to each other.
+#   (1) teacher-forced, per timestep: from the f32x3 run's own state x_t at timesteps TF_STEPS of the 50, one 16-bit NLC step: the
+#       corrected sigma (what NLC is for) within SIGMA_TOL relative for every image; and one 16-bit evaluation of the eps network at
+#       the SCHEDULED (sigma, t) - the corrected sigma picks t through a discontinuous table lookup, so eps at the corrected pair
+#       compares two different timesteps whenever the 16-bit sigma lands in the next bin - within EPS_TOL relative RMS;
+#   (2) free-running, B = 16, same x_T, after 5 / 10 / 20 / 50 timesteps: the 16-bit x0 of EVERY image closer (RMS) to the f32x3 x0
+#       of the same seed than any two f32x3 x0 of different seeds are to each other, for 5, 10 and 20 timesteps (measured on
+#       MI355X: bf16 0.31 / 0.15 / 0.14 against 0.76 / 0.24 / 0.16; f16 median 2e-3 / 2.6e-2 / 7e-2); after all 50 the
+#       trajectories have decorrelated (same-seed RMS 0.13-0.14 = the x0 std: a different, equally valid sample) and the gate is
+#       on the population: the median same-seed RMS still below the closest pair of seeds, and - at every horizon - the batch
+#       mean within POP_MEAN_TOL and the batch-mean per-image standard deviation within POP_STD_TOL of the f32x3 run's.
 TF_STEPS = (0, 1, 4, 9, 19, 29, 39, 49)
-SIGMA_TOL = {"bf16": 1e-2, "f16": 1e-3}
+SIGMA_TOL = {"bf16": 2e-2, "f16": 2.5e-3}        # 2^-8 vs 2^-11 significand: a factor 8 between them
 EPS_TOL = {"bf16": 2e-2, "f16": 3e-3}
-MEAN_TOL = {"bf16": 2e-2, "f16": 1e-2}
-STD_TOL = {"bf16": 5e-2, "f16": 2e-2}
+HORIZONS = (5, 10, 20, 50)
+POP_MEAN_TOL = 1e-2          # |batch mean of the 16-bit x0 - batch mean of the f32x3 x0|, x0 in [-1, 1] (measured <= 6.8e-3)
+POP_STD_TOL = 5e-2           # |batch mean of the per-image std, ratio - 1| (measured <= 2.8e-2)
 
 
 @pytest.fixture(scope="module")
@@ -160,11 +166,14 @@ def adm256_f32x3_run(adm256):
     try:
         x, logs = _run(exp, xT, max_steps=None, return_log=True)
         eps_tf = {}
-        for k in TF_STEPS:                                              # the f32x3 eps at its own x_t (normalised, as the sampler uses it)
-            e, _, st, _ = exp.get_denoise_vector(exp.xt_trace[k], exp.scheduler.timesteps[k].item(), exp.scheduler.sampling_sigmas[k].item(),
-                                                 exp.scheduler.sampling_sigmas[k + 1].item(), "pred", True, True)
+        S = exp.scheduler
+        for k in TF_STEPS:
+            args = (exp.xt_trace[k], S.timesteps[k].item(), S.sampling_sigmas[k].item(), S.sampling_sigmas[k + 1].item())
+            _, _, st, _ = exp.get_denoise_vector(*args, "pred", True, True)             # NLC step: the corrected sigma
+            e, _, _, _ = exp.get_denoise_vector(*args, "base", True, False)             # eps at the SCHEDULED (sigma, t): the network alone
             eps_tf[k] = (e.cpu(), st.view(-1).cpu())
-        return dict(xT=xT, x=x, xt=[t.clone() for t in exp.xt_trace], sigma=[s.clone() for s in exp.sigma_trace], eps_tf=eps_tf)
+        return dict(xT=xT, x=x, x0=[t.clone() for t in logs[3]], xt=[t.clone() for t in exp.xt_trace],
+                    sigma=[s.clone() for s in exp.sigma_trace], eps_tf=eps_tf)
     finally:
         _set_precision(exp, "bf16")
 
@@ -177,8 +186,9 @@ def test_adm256_16bit_teacher_forced_sigma_and_eps_vs_f32x3(adm256, adm256_f32x3
     worst_s, worst_e = 0.0, 0.0
     try:
         for k in TF_STEPS:
-            e, _, st, _ = exp.get_denoise_vector(ref["xt"][k], S.timesteps[k].item(), S.sampling_sigmas[k].item(),
-                                                 S.sampling_sigmas[k + 1].item(), "pred", True, True)
+            args = (ref["xt"][k], S.timesteps[k].item(), S.sampling_sigmas[k].item(), S.sampling_sigmas[k + 1].item())
+            _, _, st, _ = exp.get_denoise_vector(*args, "pred", True, True)
+            e, _, _, _ = exp.get_denoise_vector(*args, "base", True, False)
             e_ref, s_ref = ref["eps_tf"][k]
             assert torch.allclose(s_ref, ref["sigma"][k], rtol=1e-6, atol=0)          # the teacher-forced f32x3 step reproduces its run
             srel = ((st.view(-1).cpu().double() - s_ref.double()).abs() / s_ref.double()).max().item()
@@ -195,38 +205,37 @@ def test_adm256_16bit_teacher_forced_sigma_and_eps_vs_f32x3(adm256, adm256_f32x3
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 def test_adm256_16bit_sample_statistics_vs_f32x3(adm256, adm256_f32x3_run, prec):
     exp, ref = adm256, adm256_f32x3_run
+    rows = {}
     _set_precision(exp, prec)
     try:
-        x = _run(exp, ref["xT"], max_steps=None)
+        for n in HORIZONS:
+            rows[n] = _run(exp, ref["xT"], max_steps=n)
     finally:
         _set_precision(exp, "bf16")
-    a, b = x.double().flatten(1), ref["x"].double().flatten(1)
-    dmean = (a.mean(1) - b.mean(1)).abs().max().item()
-    dstd = (a.std(1) / b.std(1) - 1).abs().max().item()
-    same = (a - b).pow(2).mean(1).sqrt()                                 # [16] RMS to the f32x3 sample of the same seed
-    cross = torch.cdist(b, b) / b.shape[1] ** 0.5                         # RMS between f32x3 samples of different seeds
-    cross_min = (cross + torch.eye(16, dtype=cross.dtype) * 1e9).min().item()
-    print(f"ADM-256 {prec} vs f32x3, 50 timesteps, B=16: per-image mean diff max {dmean:.2e}, std ratio - 1 max {dstd:.2e}, RMS to the same-seed "
-          f"f32x3 sample max {same.max().item():.3e} / median {same.median().item():.3e}; min RMS between two f32x3 seeds {cross_min:.3e} "
-          f"(sample std {b.std(1).mean().item():.3e})")
-    assert torch.isfinite(x).all() and x.abs().max() <= 1.0 + 1e-6
-    assert dmean <= MEAN_TOL[prec] and dstd <= STD_TOL[prec]
-    assert same.max().item() <= cross_min
+    for n in HORIZONS:
+        a, b = rows[n].double().flatten(1), ref["x0"][n - 1].double().flatten(1)
+        same = (a - b).pow(2).mean(1).sqrt()                             # [16] RMS to the f32x3 x0 of the same seed
+        cross = torch.cdist(b, b) / b.shape[1] ** 0.5                     # RMS between f32x3 x0 of different seeds
+        cross_min = (cross + torch.eye(16, dtype=cross.dtype) * 1e9).min().item()
+        dmean = (a.mean(1) - b.mean(1)).abs().max().item()
+        pop_mean = abs(a.mean().item() - b.mean().item())
+        pop_std = abs(a.std(1).mean().item() / b.std(1).mean().item() - 1)
+        print(f"ADM-256 {prec} vs f32x3 after {n} timesteps, B=16: RMS to the same-seed f32x3 x0 max {same.max().item():.3e} / median "
+              f"{same.median().item():.3e}; min RMS between two f32x3 seeds {cross_min:.3e}; per-image mean diff max {dmean:.2e}; batch mean diff "
+              f"{pop_mean:.2e}, batch-mean std ratio - 1 {pop_std:.2e} (x0 std {b.std(1).mean().item():.3e})")
+        assert torch.isfinite(rows[n]).all() and rows[n].abs().max() <= 1.0 + 1e-6
+        assert (same.max().item() if n <= 20 else same.median().item()) <= cross_min, (n, same.max().item(), same.median().item(), cross_min)
+        assert pop_mean <= POP_MEAN_TOL and pop_std <= POP_STD_TOL, (n, pop_mean, pop_std)
 
 
-# cfg 4 / cfg 3 gates: f32 and f32x3 the north-star's 1e-3 per-pixel L-inf on the final sample.  16-bit types: at sigma_0 = 100 the
-# first x0 = xt - 100 eps turns a 1 % error of eps into an O(1) error of x0, and the +-1 clamp then saturates single pixels to the
-# opposite bound, so per-pixel L-inf says nothing there; gated are the RMS of the final sample and of the first timestep's x0, and
-# the NLC-corrected sigma (cfg 4), resp. the RMS of the final sample (cfg 3) - tripwires at ~1.5x the values measured on MI355X.
-# Measured (round 3): cfg 4 f32 5.4e-4, f32x3 2.7e-4 (L-inf); bf16 final RMS 0.074, first-x0 RMS 0.030, sigma 9.5e-4; f16 final RMS
-# 3.2e-3 ... 6.9e-2 (the two dispatches part ways at a clamp within three timesteps), first-x0 RMS 4.1e-3, sigma 1.8e-4.
-# cfg 3 f32 9.8e-6, f32x3 1.1e-5 (L-inf); bf16 RMS 5.4e-3, f16 6.8e-4 (sample RMS 1.22).
-# The corrected sigma of ONE image is one draw of a scalar whose 16-bit error spreads 5x from image to image and from one summation
-# order to the next (profiles/r03_sigma_precision.txt: bf16 0.6 ... 3.0e-3, f16 0.4 ... 3.2e-4 over six images; this test's own value
-# moved 9.5e-4 -> 2.2e-3 when the split-K hand-off and the statistics reduction changed their summation order): its gate is the top of
-# that spread x 1.5, not 1.5 x one draw.
-CELEBA_GATES = {"f32": 1e-3, "f32x3": 1e-3, "bf16": (0.11, 0.045, 4.5e-3), "f16": (0.11, 6.5e-3, 5e-4)}
-EDM_GATES = {"f32": 1e-3, "f32x3": 1e-3, "bf16": 8e-3, "f16": 1.1e-3}
+# cfg 4 / cfg 3 gates.  f32 and f32x3: the north-star's 1e-3 per-pixel L-inf on the final sample against the CPU oracle.  The 16-bit
+# types get the same kind of TOLERANCES as ADM-256 above, against the HIP f32x3 path of the same test (which the f32x3 parametrisation
+# pins to the oracle): teacher-forced from the f32x3 run's own states, the NLC-corrected sigma within SIGMA_TOL and the eps network at
+# the scheduled (sigma, t) within EPS_TOL relative RMS (cfg 4: every timestep of the run; cfg 3: four noise levels spanning the
+# schedule); the free-running 16-bit sample is reported (at sigma_0 = 100 the first x0 = xt - 100 eps turns a 1 % error of eps into an
+# O(1) error of x0 and the +-1 clamp saturates single pixels: per-pixel distances of a 16-bit trajectory say nothing there) and
+# gated only relative to the sample's own scale for cfg 3, whose six Heun steps stay correlated: RMS <= EDM_RMS_TOL x sample RMS.
+EDM_RMS_TOL = {"bf16": 1e-2, "f16": 2e-3}        # measured (round 3): 4.4e-3 and 5.6e-4 of the sample RMS
 
 
 @pytest.mark.parametrize("prec", ["f32", "f32x3", "bf16", "f16"])
@@ -304,12 +313,30 @@ def test_celebahq256_inpainting_matches_the_oracle_at_full_size(prec):
     srel = ((exp.sigma_trace[0].double() - trace["sigma_t"][0].double()).abs() / trace["sigma_t"][0].double()).max().item()
     print(f"CelebA-HQ-256 simple UNet {prec}, 3 constrained DDIM+NLC timesteps: HIP vs CPU oracle L-inf = {err:.3e}, RMS {rms:.3e} (first "
           f"timestep's x0: L-inf {first:.3e}, RMS {first_rms:.3e}; its corrected sigma {srel:.3e} relative); known pixels off by {known:.1e}")
-    assert known == 0.0
-    g = CELEBA_GATES[prec]
-    if isinstance(g, tuple):
-        assert rms <= g[0] and first_rms <= g[1] and srel <= g[2]
-    else:
-        assert err <= g
+    assert known == 0.0 and torch.isfinite(x_gpu).all()
+    if prec.startswith("f32"):
+        assert err <= 1e-3
+        return
+    # 16-bit: teacher-forced against the f32x3 path at every timestep of an f32x3 run (see the comment above the ADM-256 tests)
+    bench.set_precision(eps, bench.PRECISIONS["f32x3"]); bench.set_precision(sig, bench.PRECISIONS["f32x3"])
+    exp.denoise_loop(shape=(B, 3, res, res), xT=xT, style="pred", constrain_fn=cf.bind(y, (B, 3, res, res)), norm_eps=True,
+                     refine_prior_sigma=True, return_log=True, chunk_size=1, sigma_pred_threshold=960)
+    xts = [t.clone() for t in exp.xt_trace]
+
+    def one(k):
+        args = (xts[k], s.timesteps[k].item(), s.sampling_sigmas[k].item(), s.sampling_sigmas[k + 1].item())
+        _, _, st, _ = exp.get_denoise_vector(*args, "pred", True, True)
+        e, _, _, _ = exp.get_denoise_vector(*args, "base", True, False)
+        return e.cpu().double(), st.view(-1).cpu().double()
+
+    refs = [one(k) for k in range(steps)]
+    bench.set_precision(eps, bench.PRECISIONS[prec]); bench.set_precision(sig, bench.PRECISIONS[prec])
+    for k in range(steps):
+        e, st = one(k)
+        srel_k = ((st - refs[k][1]).abs() / refs[k][1]).max().item()
+        erel_k = ((e - refs[k][0]).pow(2).mean().sqrt() / refs[k][0].pow(2).mean().sqrt()).item()
+        print(f"  {prec} timestep {k + 1}/{steps} from the f32x3 state: corrected sigma rel {srel_k:.2e}, eps relative RMS {erel_k:.2e}")
+        assert srel_k <= SIGMA_TOL[prec] and erel_k <= EPS_TOL[prec], (k, srel_k, erel_k)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f32x3", "bf16", "f16"])
@@ -350,6 +377,30 @@ def test_edm_cifar10_matches_the_oracle_at_full_size(prec):
                             use_second_order=True)
     err = (x_gpu.cpu().double() - x_cpu.double()).abs().max().item()
     rms = (x_gpu.cpu().double() - x_cpu.double()).pow(2).mean().sqrt().item()
-    print(f"EDM CIFAR-10 SongUNet {prec} / f64 state, 6-step Heun+NLC: HIP vs CPU oracle L-inf = {err:.3e}, RMS {rms:.3e} "
-          f"(sample RMS {x_cpu.double().pow(2).mean().sqrt().item():.3e})")
-    assert x_gpu.dtype == torch.float64 and (err if prec.startswith("f32") else rms) <= EDM_GATES[prec]
+    srms = x_cpu.double().pow(2).mean().sqrt().item()
+    print(f"EDM CIFAR-10 SongUNet {prec} / f64 state, 6-step Heun+NLC: HIP vs CPU oracle L-inf = {err:.3e}, RMS {rms:.3e} (sample RMS {srms:.3e})")
+    assert x_gpu.dtype == torch.float64 and torch.isfinite(x_gpu).all()
+    if prec.startswith("f32"):
+        assert err <= 1e-3
+        return
+    assert rms <= EDM_RMS_TOL[prec] * srms
+    # teacher-forced at four noise levels spanning the schedule, against the f32x3 path on the same states
+    g = torch.Generator().manual_seed(78)
+    sig_levels = (80.0, 9.0, 1.0, 0.05)
+    xs = [(torch.randn(B, 3, 32, 32, generator=g, dtype=torch.float64) * (sg ** 2 + 0.25) ** 0.5).to("cuda:0") for sg in sig_levels]
+
+    def one(k):
+        sg = torch.tensor(sig_levels[k], dtype=torch.float64)
+        _, _, st, _ = exp.get_denoise_vector(xs[k], sg, sg * 0.5, style="pred", norm_eps=False, refine_prior_sigma=False)
+        e, _, _, _ = exp.get_denoise_vector(xs[k], sg, sg * 0.5, style="base", norm_eps=False, refine_prior_sigma=False)
+        return e.cpu().double(), st.reshape(-1).cpu().double()
+
+    bench.set_precision(eps, bench.PRECISIONS["f32x3"]); bench.set_precision(sig, bench.PRECISIONS["f32x3"])
+    refs = [one(k) for k in range(len(sig_levels))]
+    bench.set_precision(eps, bench.PRECISIONS[prec]); bench.set_precision(sig, bench.PRECISIONS[prec])
+    for k, sg in enumerate(sig_levels):
+        e, st = one(k)
+        srel_k = ((st - refs[k][1]).abs() / refs[k][1].abs()).max().item()
+        erel_k = ((e - refs[k][0]).flatten(1).pow(2).mean(1).sqrt() / refs[k][0].flatten(1).pow(2).mean(1).sqrt()).max().item()
+        print(f"  {prec} at sigma {sg}: corrected sigma rel {srel_k:.2e}, eps relative RMS (max over images) {erel_k:.2e}")
+        assert srel_k <= SIGMA_TOL[prec] and erel_k <= EPS_TOL[prec], (sg, srel_k, erel_k)

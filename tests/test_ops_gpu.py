@@ -29,6 +29,14 @@ def _dev():
     return torch.device("cuda:0")
 
 
+def _totals(st):
+    """Ride-along GroupNorm statistics, int64 [B, C/g, 4] = (sum.hi, sum.lo, sumsq.hi, sumsq.lo) fixed-point totals
+    (include/nlc_hip.h: nlc_conv_desc.stats_out) -> double [B, C/g, 2] = (sum, sum of squares) on the CPU."""
+    assert st.dtype == torch.int64 and st.shape[-1] == 4
+    t = st.cpu().double()
+    return torch.stack([t[..., 0] + t[..., 1] * 2.0 ** -44, t[..., 2] + t[..., 3] * 2.0 ** -44], dim=-1)
+
+
 def _tol(dtype):
     return {torch.float32: 2e-4, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
 
@@ -491,8 +499,8 @@ def test_conv_first(dtype):
     assert (st is not None) == (dtype != torch.float32)
     if st is not None:
         ch = got.float().cpu().view(2, 32 * 64, 32, 8)
-        assert (st.double().sum(1).cpu()[..., 0] - ch.double().sum(dim=(1, 3))).abs().max() < 5e-2
-        assert ((st.double().sum(1).cpu()[..., 1] - (ch.double() ** 2).sum(dim=(1, 3))) / (ch.double() ** 2).sum(dim=(1, 3))).abs().max() < 5e-4
+        assert (_totals(st)[..., 0] - ch.double().sum(dim=(1, 3))).abs().max() < 5e-2
+        assert ((_totals(st)[..., 1] - (ch.double() ** 2).sum(dim=(1, 3))) / (ch.double() ** 2).sum(dim=(1, 3))).abs().max() < 5e-4
 
 
 def test_row_sumsq_and_quantile():
@@ -534,11 +542,11 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy, t1
     st = getattr(y, "_nlc_stats", None)
     # partials per image: 4 per 16x16 patch from the halo kernel, 2 per 128-pixel tile from conv_fast
     P = (H // 16) * (W // 16) * 4 if conv_policy == "halo" else (H * W // 128) * 2
-    assert st is not None and st.shape == (B, P, Cout // 8, 2)
+    assert st is not None and st.shape == (B, Cout // 8, 4)
     yf = y.float().cpu()                                              # [B,H,W,C] stored values
     chunks = yf.view(B, H * W, Cout // 8, 8)
     ref_sum, ref_sq = chunks.sum(dim=(1, 3)), (chunks.double() ** 2).sum(dim=(1, 3))
-    got = st.double().sum(dim=1).cpu()
+    got = _totals(st)
     assert (got[..., 0] - ref_sum.double()).abs().max() < 1e-2 * ref_sum.abs().max().clamp(min=1.0)
     # (every emitter sums the STORED, bf16-rounded values; what is left is f32 summation order)
     assert ((got[..., 1] - ref_sq) / ref_sq).abs().max() < 5e-4
@@ -557,11 +565,11 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy, t1
     ws = torch.randn(256, 512, 3, 3, generator=g) / math.sqrt(512 * 9)
     ys = ops.conv2d(_nhwc(xs, t16), ops.pack_conv(ws, b, t16, _dev()))
     sts = getattr(ys, "_nlc_stats", None)
-    assert sts is not None and sts.shape == (2, 64, 32, 2)
+    assert sts is not None and sts.shape == (2, 32, 4)
     chs = ys.float().cpu().view(2, 64, 32, 8)
     ref_s = chs.double().sum(dim=(1, 3))              # 512 stored values per chunk
-    assert (sts.double().sum(1).cpu()[..., 0] - ref_s).abs().max() < 2e-3 * ref_s.abs().max()
-    assert ((sts.double().sum(1).cpu()[..., 1] - (chs.double() ** 2).sum(dim=(1, 3))) / (chs.double() ** 2).sum(dim=(1, 3))).abs().max() < 2e-3
+    assert (_totals(sts)[..., 0] - ref_s).abs().max() < 2e-3 * ref_s.abs().max()
+    assert ((_totals(sts)[..., 1] - (chs.double() ** 2).sum(dim=(1, 3))) / (chs.double() ** 2).sum(dim=(1, 3))).abs().max() < 2e-3
     cat = torch.cat([yf, y2.float().cpu()], dim=-1).permute(0, 3, 1, 2)
     ref = F.silu(F.group_norm(cat, 32, gamma.cpu(), beta.cpu(), eps=1e-5)).permute(0, 2, 3, 1)
     scale = ref.abs().max().item()
@@ -600,11 +608,11 @@ def test_ride_along_statistics_under_the_production_dispatch(case, t16):
         ops.CONV_POLICY = old
     st = getattr(y, "_nlc_stats", None)
     gran = ops.stats_granule(Cout)                                   # 4 for the 128-channel case (32 groups of 4), else 8
-    assert st is not None and st.shape == (B, P_expect, Cout // gran, 2), (what, None if st is None else st.shape)
+    assert st is not None and st.shape == (B, Cout // gran, 4), (what, None if st is None else st.shape)
     ref = F.conv2d(_rt(x, t16), _rt(w, t16), b, padding=1) + _rt(res, t16)
     _close(y.permute(0, 3, 1, 2), ref, 2e-2, what)
     ch = y.float().cpu().view(B, H * W, Cout // gran, gran).double()
-    got = st.double().sum(dim=1).cpu()
+    got = _totals(st)
     s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
     assert (got[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0), what
     assert ((got[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3, what
@@ -644,9 +652,9 @@ def test_groupnorm_with_four_channel_groups_uses_ride_along_statistics(policy, t
         ops.CONV_POLICY = old
     for y in ys:
         st = getattr(y, "_nlc_stats", None)
-        assert st is not None and st.shape[2] == C // 4, "expected statistics per 4 channels"
+        assert st is not None and st.shape[1] == C // 4, "expected statistics per 4 channels"
         ch = y.float().cpu().view(B, H * W, C // 4, 4).double()
-        got = st.double().sum(dim=1).cpu()
+        got = _totals(st)
         assert (got[..., 0] - ch.sum(dim=(1, 3))).abs().max() <= 3e-3 * max(ch.sum(dim=(1, 3)).abs().max().item(), 1.0)
         assert ((got[..., 1] - (ch ** 2).sum(dim=(1, 3))) / (ch ** 2).sum(dim=(1, 3))).abs().max() <= 2e-3
     tol = 2e-2 if t16 == torch.bfloat16 else 3e-3
@@ -862,12 +870,12 @@ def test_conv2d_halo_kernel_split_k(case, t16):
     tiles = B * (Ho // 16) * (Wo // 16) * (Cout // 128)
     gran = ops.stats_granule(Cout)
     if tiles * case["ks"] >= 128:
-        assert st is not None and st.shape == (B, (Ho // 16) * (Wo // 16) * 4, Cout // gran, 2), "the halo kernel did not take this launch"
+        assert st is not None and st.shape == (B, Cout // gran, 4), "the halo kernel did not take this launch"
     _close(got.permute(0, 3, 1, 2), ref, 2e-2, "conv2d (halo split-K)")
     assert (got.float() - plain.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
     if st is not None:
         ch = got.float().cpu().view(B, Ho * Wo, Cout // gran, gran).double()
-        tot = st.double().sum(dim=1).cpu()
+        tot = _totals(st)
         s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
         assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
         assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-silu", action="store_true", help="normalise only (memory-side rate of the same access pattern)")
-    ap.add_argument("--prestats", action="store_true", help="statistics 'ride along' (zeros attached): times finalize + apply only, 1 read + 1 write")
+    ap.add_argument("--prestats", action="store_true", help="statistics 'ride along' (zeros attached): times the apply launch only (it derives its coefficients from the totals), 1 read + 1 write")
     args = ap.parse_args()
     global SILU
     SILU = not args.no_silu
@@ -38,9 +38,9 @@ def main():
         x1 = torch.randn(args.batch, H, H, c1, device=dev).to(dt) if c1 else None
         C = c0 + c1
         if args.prestats:
-            x0._nlc_stats = torch.zeros(args.batch, (H // 16) ** 2 * 4 if H >= 16 else H * H, c0 // 8, 2, device=dev)
+            x0._nlc_stats = torch.zeros(args.batch, c0 // 8, 4, device=dev, dtype=torch.int64)       # totals (zeros: timing only)
             if x1 is not None:
-                x1._nlc_stats = torch.zeros(args.batch, x0._nlc_stats.shape[1], c1 // 8, 2, device=dev)
+                x1._nlc_stats = torch.zeros(args.batch, c1 // 8, 4, device=dev, dtype=torch.int64)
         g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
         for _ in range(3):
             ops.groupnorm(x0, g, b, groups=32, eps=1e-5, silu=SILU, x1=x1)

@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--make-f64", default="", metavar="FILE", help="CPU only: run the oracle in float64 and save its trajectory (no GPU needed)")
     ap.add_argument("--f64-trace", default="", metavar="FILE", help="a trajectory written by --make-f64: adds the distances to it")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--mixed", nargs="*", type=int, default=[], metavar="K",
+                    help="sigma-adaptive precision: timesteps 0..K-1 in f32x3, K..end in --mixed-low, for every K given (the error a timestep "
+                         "injects into the state is (sigma_t - sigma_prev) * d(eps), which shrinks with sigma)")
+    ap.add_argument("--mixed-low", default="f16", choices=["f16", "bf16"])
     args = ap.parse_args()
     ns = argparse.Namespace(tiny=False, batch=1, timesteps=50, dry_run=bool(args.make_f64), dtype="f32")
     dev = torch.device("cpu" if args.make_f64 else "cuda:0")
@@ -100,7 +104,7 @@ def main():
            "oracle_seconds": secs, "x0_rms_final": float(x0_ref[-1].double().pow(2).mean().sqrt()), "precisions": {}}
     f64 = None
     if args.f64_trace:
-        f64 = torch.load(args.f64_trace)
+        f64 = torch.load(args.f64_trace, weights_only=False)          # our own file (written by --make-f64)
         assert torch.equal(f64["xT"], xT) and f64["timesteps"] >= args.timesteps
 
         def to_f64(x0s, sigs):
@@ -146,6 +150,32 @@ def main():
             print(f"{name} vs f64: x0 L-inf first {d['x0_linf_per_timestep'][0]:.3e}  final {d['x0_linf_per_timestep'][-1]:.3e}  RMS final "
                   f"{d['x0_rms_per_timestep'][-1]:.3e};  ratio to CPU-f32's own distance: L-inf max {max(d['ratio_to_cpu_f32_linf']):.2f} "
                   f"median {sorted(d['ratio_to_cpu_f32_linf'])[len(d['ratio_to_cpu_f32_linf']) // 2]:.2f}, RMS max {max(d['ratio_to_cpu_f32_rms']):.2f}", flush=True)
+    if args.mixed:
+        N = args.timesteps
+        run = lambda **kw: wl.exp.denoise_loop(shape=(1, 3, 256, 256), style="pred", norm_eps=True, refine_prior_sigma=True, return_log=True,
+                                               chunk_size=1, sigma_pred_threshold=960, max_steps=N, **kw)
+        for m in (wl.exp.model, wl.exp.sigma_model):
+            bench.set_precision(m, bench.PRECISIONS["f32x3"])
+        x_hi, _ = run(xT=xT)
+        xts = [t.clone() for t in wl.exp.xt_trace]
+        out["mixed"] = {"low": args.mixed_low, "what": f"timesteps 0..K-1 in f32x3, K..{N - 1} in {args.mixed_low}; final clipped x0 vs the CPU-f32 oracle"
+                                                       + (" and vs the f64 trajectory" if f64 is not None else ""), "K": {}}
+        for K in sorted(set(args.mixed)):
+            if not 0 <= K <= N:
+                continue
+            if K == N:
+                x = x_hi
+            else:
+                for m in (wl.exp.model, wl.exp.sigma_model):
+                    bench.set_precision(m, bench.PRECISIONS[args.mixed_low])
+                x, _ = run(xT=xts[K], start_step=K)
+            d = x.double().cpu() - x0_ref[N - 1].double()
+            row = {"final_linf_vs_oracle": float(d.abs().max()), "final_rms_vs_oracle": float(d.pow(2).mean().sqrt())}
+            if f64 is not None:
+                d64 = x.double().cpu() - f64["x0"][N - 1]
+                row.update(final_linf_vs_f64=float(d64.abs().max()), final_rms_vs_f64=float(d64.pow(2).mean().sqrt()))
+            out["mixed"]["K"][str(K)] = row
+            print(f"mixed f32x3[0,{K}) + {args.mixed_low}[{K},{N}): " + "  ".join(f"{k} {v:.3e}" for k, v in row.items()), flush=True)
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(out))
     print("wrote", args.out)
