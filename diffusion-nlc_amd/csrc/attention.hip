@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
 //   * O^T has the query on the lane as well, so the online-softmax rescale and the final 1 / l are lane-local too.
 // exp(x) is evaluated as exp2(x log2 e) with the multiply folded into one FMA per score.
 constexpr int FQ_ROWS = 256, FKV = 64;
-constexpr int ATTN_W = 8, ATTN_NST = 2;                // the shipped shape (chosen by measurement, see below)                 // dispatch granularity of T (every workgroup shape divides it)
+constexpr int ATTN_W = 8, ATTN_NST = 2, ATTN_QB = 1;   // the shipped shape: 8 waves x 32 queries (chosen by measurement, see below); T % 256 == 0
 constexpr int F_SUB = 1;                               // 64-key tiles per stage (= per barrier); 2 measured slower (55.9 vs 51.7 us at T = 1024)
 constexpr int F_TILE = FKV * 128;                      // one K or V tile: 64 rows x 128 B
 constexpr int F_STAGE = F_SUB * F_TILE;
@@ -290,10 +290,19 @@ template <int TP> __device__ __forceinline__ void dma_wait_tiles(int tiles) {
 //   * the row sums l come from the matrix pipe: one more MFMA per k-step with an all-ones A operand and the same P^T fragment
 //     (every row of the result is sum_k P[k][q]; only register 0 is kept consistent), instead of 32 adds per tile - and they sum
 //     the ROUNDED probabilities the PV product uses.
-template <typename T, bool BASE2, int W, int NST>
-__global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
+// QB = 32-query blocks per wave.  QB = 2 (round 4; instantiate <T, BASE2, 4, NST, 2> to measure): a wave owns 64 queries; every K
+// fragment read feeds the S^T MFMAs of both blocks and every V^T fragment read the O^T MFMAs of both - half the LDS fragment reads per
+// MFMA - and the two blocks are independent dependency chains inside one wave.  ~2x the registers (230 VGPRs: two waves per SIMD
+// instead of four), so W = 4 waves per workgroup keeps 256 queries per workgroup.  Measured level with QB = 1 (profiles/r04_summary.md:
+// 48.3 vs 47.6 us under the counters at T = 1024, 12.9 vs 12.2 us at T = 256; LDS instructions halved, time a wave waits for LDS
+// 2.07 M -> 0.44 M cycles, waves parked 36 % -> 24 %, matrix pipe 36.6 % vs 37.8 % busy): neither the fragment reads nor the lockstep
+// of the phases bound this kernel.  What does: one v_exp_f32 per score is a quarter-rate (16-cycle) instruction - 32 per lane and tile
+// = 512 issue cycles per wave against 640 matrix cycles, ~30 % of all SIMD cycles on top of the 38 % the MFMAs take - and the two
+// only overlap across waves.  QB = 1 ships.
+template <typename T, bool BASE2, int W, int NST, int QB = 1>
+__global__ __launch_bounds__(W * 64, QB == 2 ? 2 : (W == 8 ? 2 : 4)) void attn_d64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
     constexpr int F_NST = NST;
-    constexpr int WG_ROWS = W * 32;                        // queries per workgroup
+    constexpr int WG_ROWS = W * 32 * QB;                   // queries per workgroup
     constexpr int PP = 8 / W;                              // DMA pieces (8 rows x 128 B) of K, and of V, per wave and tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -310,18 +319,19 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
         lin = (xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq) + idx;
     }
     const int pair = lin / nqb, qblk = lin - pair * nqb;
-    const int b = pair / H, hd = pair - b * H, q0 = qblk * WG_ROWS + wave * 32;
+    const int b = pair / H, hd = pair - b * H, q0 = qblk * WG_ROWS + wave * 32 * QB;
     const int64_t tok = (int64_t)3 * H * 64;            // elements between consecutive tokens
     const T* qb = qkv + (int64_t)b * Tn * tok + (int64_t)hd * 64;
     const T* kb = qb + (int64_t)H * 64;
     const T* vb = qb + (int64_t)2 * H * 64;
 
     // Q^T fragments (B operand): lane (q, h) holds Q[q0 + q][16 s + 8 h + j], j = 0..7
-    uint4 qf[4];
-    {
-        const T* qp = qb + (int64_t)(q0 + q) * tok + h * 8;
+    uint4 qf[QB][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16);
+    for (int u = 0; u < QB; ++u) {
+        const T* qp = qb + (int64_t)(q0 + 32 * u + q) * tok + h * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const uint4*>(qp + s * 16);
     }
 
     // this wave's DMA piece of every tile: rows 8 wave .. 8 wave + 7; lane -> (row, 16-byte slot), source chunk = slot ^ swizzle(row)
@@ -359,10 +369,14 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
 #pragma unroll
         for (int db = 0; db < 2; ++db) { vo[ks][db][0] = voff(ks, db, 0); vo[ks][db][1] = voff(ks, db, 1); }
 
-    f32x16_t o0, o1, lacc;                               // O^T blocks: d = 32 db + (reg & 3) + 8 (reg >> 2) + 4 h, query on the lane; lacc[0] = row sum
+    f32x16_t o0[QB], o1[QB], lacc[QB];                   // O^T blocks: d = 32 db + (reg & 3) + 8 (reg >> 2) + 4 h, query on the lane; lacc[0] = row sum
+    float mrun[QB], moff[QB];                            // running maximum and current offset of this lane's queries, log2 units
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; lacc[r] = 0.f; }
-    float mrun = -1e30f, moff = 0.f;                     // running maximum and current offset of this lane's query, log2 units
+    for (int u = 0; u < QB; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[u][r] = 0.f; o1[u][r] = 0.f; lacc[u][r] = 0.f; }
+        mrun[u] = -1e30f; moff[u] = 0.f;
+    }
     constexpr float L2E = 1.44269504088896340736f;
     const unsigned one2 = std::is_same<T, bf16_raw>::value ? 0x3F803F80u : 0x3C003C00u;      // two 1.0 in T
     const uint4 ones = make_uint4(one2, one2, one2, one2);
@@ -385,16 +399,27 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
         const char* Kt = smem + st * F_STAGE + u * F_TILE;
         const char* Vt = smem + (F_NST + st) * F_STAGE + u * F_TILE;
         // ---- S^T = K Q^T : two 32-key blocks
-        f32x16_t s0, s1;
+        f32x16_t sA[QB], sB[QB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        for (int u = 0; u < QB; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sA[u][r] = 0.f; sB[u][r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const uint4 ka = *reinterpret_cast<const uint4*>(Kt + koff[s]);
             const uint4 kc = *reinterpret_cast<const uint4*>(Kt + koff[s] + 4096);
-            s0 = Mfma16<T>::run32(ka, qf[s], s0);
-            s1 = Mfma16<T>::run32(kc, qf[s], s1);
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {                  // one K fragment read, QB query blocks
+                sA[u] = Mfma16<T>::run32(ka, qf[u][s], sA[u]);
+                sB[u] = Mfma16<T>::run32(kc, qf[u][s], sB[u]);
+            }
         }
+#pragma unroll
+      for (int u = 0; u < QB; ++u) {
+        f32x16_t& s0 = sA[u];
+        f32x16_t& s1 = sB[u];
+        float& mrun_ = mrun[u];
+        float& moff_ = moff[u];
         // ---- tile maximum of the RAW scores (v_max3_f32 from inline asm: fmaxf() on an MFMA output makes hipcc insert a quieting
         // v_max(x, x) per element first).  The first maximum is plain C so that the compiler itself pads the MFMA -> VALU read
         // hazard of both accumulators; every asm statement depends on it through `tm`.
@@ -409,26 +434,26 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tm), __float_as_uint(tm), false, false);
             tm = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));      // lanes l and l ^ 32 hold the two halves of one row
         }
-        const float mnew = fmaxf(mrun, BASE2 ? tm : tm * L2E);
+        const float mnew = fmaxf(mrun_, BASE2 ? tm : tm * L2E);
         // an offset is (re)chosen when the running maximum leaves [-64, 64] relative to it; on the first tile also when it lies
         // far BELOW (all logits very negative: 2^s would underflow)
         // (bf16 has f32's exponent range; an f16 probability must stay below 2^16 and well above 2^-24, so there the window is +-8)
         constexpr float WIN = std::is_same<T, bf16_raw>::value ? 64.f : 8.f;
-        const float rel = mnew - moff;
-        const bool need = rel > WIN || (mrun < -1e29f && rel < -WIN);
-        mrun = mnew;
-        if (__builtin_amdgcn_ballot_w64(need || moff != 0.f) != 0) {
+        const float rel = mnew - moff_;
+        const bool need = rel > WIN || (mrun_ < -1e29f && rel < -WIN);
+        mrun_ = mnew;
+        if (__builtin_amdgcn_ballot_w64(need || moff_ != 0.f) != 0) {
             // general path (rare): some query of this wave carries an offset - subtract it IN PLACE, then the common exponentials
             if (__builtin_amdgcn_ballot_w64(need) != 0) {
-                const float mo = need ? mnew : moff;
+                const float mo = need ? mnew : moff_;
                 // nothing is accumulated before the first tile; afterwards need implies mo > moff, so alpha < 1
-                const float alpha = (lacc[0] == 0.f && o0[0] == 0.f) ? 1.f : __builtin_amdgcn_exp2f(moff - mo);
-                moff = mo;
+                const float alpha = (lacc[u][0] == 0.f && o0[u][0] == 0.f) ? 1.f : __builtin_amdgcn_exp2f(moff_ - mo);
+                moff_ = mo;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-                lacc[0] *= alpha;
+                for (int r = 0; r < 16; ++r) { o0[u][r] *= alpha; o1[u][r] *= alpha; }
+                lacc[u][0] *= alpha;
             }
-            const float sub = BASE2 ? moff : moff * (1.0f / L2E);       // in the units of the raw scores
+            const float sub = BASE2 ? moff_ : moff_ * (1.0f / L2E);       // in the units of the raw scores
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s0[r] -= sub; s1[r] -= sub; }
         }
@@ -438,22 +463,26 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
             s0[r] = __builtin_amdgcn_exp2f(BASE2 ? s0[r] : s0[r] * L2E);
             s1[r] = __builtin_amdgcn_exp2f(BASE2 ? s1[r] : s1[r] * L2E);
         }
+      }
         // ---- O^T += V^T P^T and l += 1^T P^T : P^T k-steps come straight from the score registers
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            uint4 pf;
-            if constexpr (std::is_same<T, bf16_raw>::value) {
-                bf16x8_t pb;
+            uint4 pf[QB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)((ks < 2 ? s0 : s1)[(ks & 1) * 8 + j]);
-                pf = __builtin_bit_cast(uint4, pb);
-            } else {
-                f16x8_t ph;
+            for (int u = 0; u < QB; ++u) {
+                if constexpr (std::is_same<T, bf16_raw>::value) {
+                    bf16x8_t pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ph[j] = (f16_raw)((ks < 2 ? s0 : s1)[(ks & 1) * 8 + j]);
-                pf = __builtin_bit_cast(uint4, ph);
+                    for (int j = 0; j < 8; ++j) pb[j] = (__bf16)((ks < 2 ? sA[u] : sB[u])[(ks & 1) * 8 + j]);
+                    pf[u] = __builtin_bit_cast(uint4, pb);
+                } else {
+                    f16x8_t ph;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ph[j] = (f16_raw)((ks < 2 ? sA[u] : sB[u])[(ks & 1) * 8 + j]);
+                    pf[u] = __builtin_bit_cast(uint4, ph);
+                }
+                lacc[u] = Mfma16<T>::run32(ones, pf[u], lacc[u]);
             }
-            lacc = Mfma16<T>::run32(ones, pf, lacc);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vt + vo[ks][db][0]));
@@ -463,8 +492,11 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
                 va.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
                 va.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
                 va.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
-                if (db == 0) o0 = Mfma16<T>::run32(va, pf, o0);
-                else o1 = Mfma16<T>::run32(va, pf, o1);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {              // one V^T fragment, QB query blocks
+                    if (db == 0) o0[u] = Mfma16<T>::run32(va, pf[u], o0[u]);
+                    else o1[u] = Mfma16<T>::run32(va, pf[u], o1[u]);
+                }
             }
         }
       }
@@ -473,35 +505,38 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 2 : 4) void attn_d64_kernel(const 
         __syncthreads();                                       // ... and everybody's are published; tile t's stage is free
     }
     // ---- finish: normalise by the row sum (every row of lacc is the same sum), store 4 consecutive channels (8 bytes) per register quad
-    const float inv = 1.0f / lacc[0];
-    T* op = out + ((int64_t)b * Tn + q0 + q) * ((int64_t)H * 64) + (int64_t)hd * 64 + 4 * h;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int u = 0; u < QB; ++u) {
+        const float inv = 1.0f / lacc[u][0];
+        T* op = out + ((int64_t)b * Tn + q0 + 32 * u + q) * ((int64_t)H * 64) + (int64_t)hd * 64 + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x16_t& o = db ? o1 : o0;
-            const float ov[8] = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv, 0.f, 0.f, 0.f, 0.f};
-            const uint4 pk = f32_to_chunk<T>(ov);
-            *reinterpret_cast<uint2*>(op + db * 32 + 8 * g) = make_uint2(pk.x, pk.y);
-        }
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16_t& o = db ? o1[u] : o0[u];
+                const float ov[8] = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv, 0.f, 0.f, 0.f, 0.f};
+                const uint4 pk = f32_to_chunk<T>(ov);
+                *reinterpret_cast<uint2*>(op + db * 32 + 8 * g) = make_uint2(pk.x, pk.y);
+            }
+    }
 }
 
 
-template <typename T, bool BASE2, int W, int NST>
+template <typename T, bool BASE2, int W, int NST, int QB>
 int launch_d64v(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
     constexpr int LDS = 2 * NST * F_STAGE;
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel<T, BASE2, W, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_d64_kernel<T, BASE2, W, NST, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    hipLaunchKernelGGL((attn_d64_kernel<T, BASE2, W, NST>), dim3((Tn / (W * 32)) * H * B), dim3(W * 64), LDS, st, (const T*)qkv, (T*)out, Tn, H);
+    hipLaunchKernelGGL((attn_d64_kernel<T, BASE2, W, NST, QB>), dim3((Tn / (W * 32 * QB)) * H * B), dim3(W * 64), LDS, st, (const T*)qkv, (T*)out, Tn, H);
     NLC_CHECK_LAUNCH("nlc_attention(d64)");
     return NLC_OK;
 }
 
 template <typename T, bool BASE2>
 int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st) {
-    return launch_d64v<T, BASE2, ATTN_W, ATTN_NST>(qkv, out, B, Tn, H, st);
+    return launch_d64v<T, BASE2, ATTN_W, ATTN_NST, ATTN_QB>(qkv, out, B, Tn, H, st);
 }
 
 template <typename T, int D>
