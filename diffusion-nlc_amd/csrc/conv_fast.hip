@@ -442,7 +442,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
             st.emit_lane(p.stats, b, p.Cout, n, p.stats_gran);
         }
     };
-    bool done = false;
+    bool done = false, stats_emitted = false;
     if constexpr (sizeof(T) == 2) {
         // hot path (bf16, whole 16-channel slice, NHWC, no per-image embedding): option switches hoisted out of the
         // element loops (see conv_halo.hip: the general path costs ~19 VALU per output element)
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
             const int act = p.act;
             // all residual chunks are requested before the first row is stored (the compiler keeps a row's loads behind the previous
             // row's stores - it cannot see that `out` and `res` do not alias: four exposed memory latencies per tile)
-            uint4 rq0[4], rq1[4];
+            uint4 rq0[4], rq1[4], pka[4], pkb[4];
             if (has_res) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -489,15 +489,30 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
 #pragma unroll
                     for (int k = 0; k < 16; ++k) v[k] = gelu_erf(v[k]);
                 }
-                T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
                 const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
-                *reinterpret_cast<uint4*>(op) = pk0;
-                *reinterpret_cast<uint4*>(op + 8) = pk1;
+                pka[i] = pk0; pkb[i] = pk1;
                 if (has_stats) {         // of the STORED (rounded) values - what the GroupNorm that follows reads
                     if (pix_stats) st16.zero();
                     st16.add_chunk<T>(0, pk0); st16.add_chunk<T>(1, pk1);
                     if (pix_stats) emit_pix(st16, m);       // split launches: a tile may straddle images -> per 16-pixel row
                 }
+            }
+            // The statistics atomics go out BEFORE the row stores: they are performed at the memory side (device scope across the
+            // XCDs' L2s) and take a few microseconds to retire - issued last, behind the stores, that latency was the tail of every
+            // small launch (+2 ... 3 us per conv_fast launch when the statistics became atomics; the kernel cannot end before they do).
+            if (has_stats && !pix_stats) {   // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
+                st16.emit_row(p.stats, m0 / HWo, p.Cout, n, p.stats_gran, fr);
+                stats_emitted = true;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + fr;
+                if (m >= p.M) continue;
+                T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n;
+                *reinterpret_cast<uint4*>(op) = pka[i];
+                *reinterpret_cast<uint4*>(op + 8) = pkb[i];
             }
             done = true;
         }
@@ -575,7 +590,7 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (p.stats && !pix_stats) {       // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
+        if (p.stats && !pix_stats && !stats_emitted) {       // (general epilogue) whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
 #pragma unroll
             for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
             st16.emit_row(p.stats, m0 / HWo, p.Cout, n, p.stats_gran, fr);
