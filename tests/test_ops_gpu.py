@@ -1098,3 +1098,46 @@ def test_conv2d_residual_read_nearest_2x_upsampled(case):
         ops.CONV_POLICY = old
     _close(got.permute(0, 3, 1, 2), ref, _tol(dtype), f"conv2d res_upsample2x ({policy})")
     assert torch.equal(got, same)                 # identical arithmetic to the materialised upsample
+
+
+ADM_B1_SHAPES = [
+    # (Cin, H, Cout): the 3x3 shapes of ADM-256 at B = 1 that BOTH kernels can take (the 256x256 ones scaled to 128x128)
+    (256, 128, 256), (512, 64, 256), (512, 64, 512), (1024, 32, 512), (1024, 16, 1024), (768, 32, 512),
+]
+
+
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+@pytest.mark.parametrize("shape", ADM_B1_SHAPES, ids=lambda s: f"{s[0]}to{s[2]}at{s[1]}")
+def test_halo_and_fast_kernels_agree_to_f32_rounding(shape, t16):
+    """The same 16-bit-MFMA / f32-accumulate arithmetic in two kernels (LDS-halo forced vs forbidden) on the ADM-256 shapes at B = 1:
+    the outputs are the same f32 sums rounded once to the storage type, up to the order of the f32 additions - at most one rounding
+    step of the storage type (plus the f32 sums' own few-ulp order dependence) apart on every element and identical on nearly all
+    of them, and the ride-along GroupNorm totals agree to f32 rounding.  (A 10x gap between the two dispatches in a trajectory-level statistic is one draw of the corrected sigma, not a kernel
+    difference: DESIGN.md §2.)"""
+    from diffusion_nlc_amd import ops
+    Cin, H, Cout = shape
+    g = torch.Generator().manual_seed(_seed(shape))
+    x = _nhwc(torch.randn(1, Cin, H, H, generator=g), t16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pw = ops.pack_conv(w, b, t16, _dev())
+    old = ops.CONV_POLICY
+    outs = {}
+    try:
+        for pol in ("halo", "no_halo"):
+            ops.CONV_POLICY = pol
+            y = ops.conv2d(x, pw)
+            outs[pol] = (y.float().cpu(), _totals(ops.ride_stats(y)))
+    finally:
+        ops.CONV_POLICY = old
+    (a, sa), (c, sc) = outs["halo"], outs["no_halo"]
+    ulp = 2.0 ** (-7 if t16 == torch.bfloat16 else -10)           # spacing of the storage type relative to the value: at most 2^-7 / 2^-10
+    d = (a - c).abs()
+    # one rounding step of the storage type + the f32 sums' own order-dependence (K = 9 Cin terms: a few f32 ulps of the LARGEST
+    # outputs, which for outputs near zero is many ulps of the small value itself)
+    tol = ulp * torch.maximum(a.abs(), c.abs()) * 1.01 + 4e-6 * a.abs().max()
+    assert (d <= tol).all(), f"max {(d / tol).max().item():.2f} x the tolerance"
+    assert (d > 0).float().mean().item() < 0.05                      # different summation order flips a rounding on a few per cent
+    scale = sa[..., 1].abs().max()
+    assert (sa[..., 0] - sc[..., 0]).abs().max() <= 2e-3 * sa[..., 0].abs().max().clamp_min(1.0)
+    assert (sa[..., 1] - sc[..., 1]).abs().max() <= 2e-3 * scale
