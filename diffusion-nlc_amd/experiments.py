@@ -220,7 +220,7 @@ class ExperimentDiffusion:
         return st
 
     def _nlc_step(self, xt, t_sched, sigma_sched, sigma_prev_sched, style, norm_eps, refine, per_sample=False,
-                  prev_is_ratio=False):
+                  prev_is_ratio=False, chunk_size=1):
         """get_denoise_vector (src/experiments.py:399-460) on the device.  Returns (eps_out, eps_sumsq).
         ``per_sample``: the scheduled sigma_t / t are the per-sample vectors already in the device state
         (projection_loop, image_sample.py:461-497); ``prev_is_ratio``: sigma_prev = sigma_t * sigma_prev_sched."""
@@ -245,7 +245,14 @@ class ExperimentDiffusion:
             r = self.sigma_model.run_nhwc(feat)
             ops.sigma_correct(r, style != "pred", S.device_sigmas(self.device), st["sigma_t"], st["sigma_prev"], st["t"],
                               st["c_in"], t_slopes=slopes)
-        eps_out = self.model.run(xt, st["t"], mode="forward", in_scale=st["c_in"])
+        # the reference evaluates the eps network on len(xt) // chunk_size samples at a time (src/experiments.py:436-450: memory
+        # only - no op of the networks couples samples, so the result is the same bit for bit; tests/test_loop_gpu.py)
+        micro = max(B // max(int(chunk_size), 1), 1)
+        if micro >= B:
+            eps_out = self.model.run(xt, st["t"], mode="forward", in_scale=st["c_in"])
+        else:
+            eps_out = torch.cat([self.model.run(xt[i:i + micro], st["t"][i:i + micro], mode="forward", in_scale=st["c_in"][i:i + micro]).clone()
+                                 for i in range(0, B, micro)])
         C = self.data_shape[0]
         if self.learn_epsvar and eps_out.shape[1] != 2 * C:
             raise NlcError("learn_epsvar expects a 2C-channel network output")
@@ -310,7 +317,8 @@ class ExperimentDiffusion:
         """Reference-shaped wrapper: returns (eps_mean, eps_logvar, sigma_t, sigma_prev) as (B,..) GPU tensors."""
         xt = xt.to(self.device, torch.float32).contiguous()
         B, C = xt.shape[0], self.data_shape[0]
-        eps_out, es = self._nlc_step(xt, float(t), float(sigma_t), float(sigma_prev), style, norm_eps, refine_prior_sigma)
+        eps_out, es = self._nlc_step(xt, float(t), float(sigma_t), float(sigma_prev), style, norm_eps, refine_prior_sigma,
+                                     chunk_size=chunk_size)
         st = self._state(B)
         eps = eps_out[:, :C].contiguous()
         if es is not None:
@@ -379,7 +387,8 @@ class ExperimentDiffusion:
             cur_style, cur_refine = style, bool(refine_prior_sigma)
             if t > sigma_pred_threshold:
                 cur_style, cur_refine = "base", False
-            eps_out, es = self._nlc_step(xt, t, sig_host[ind], sig_host[ind + 1], cur_style, bool(norm_eps), cur_refine)
+            eps_out, es = self._nlc_step(xt, t, sig_host[ind], sig_host[ind + 1], cur_style, bool(norm_eps), cur_refine,
+                                         chunk_size=chunk_size)
             use_constraint = constrain_fn is not None and (free_const_steps <= 0 or ind <= free_const_steps)
             x0_hat, x0, x_prev, eps_used = self._sched_update(xt, eps_out, es, ind, constrain_fn, use_constraint, return_log,
                                                              noise_list)
@@ -477,7 +486,7 @@ class ExperimentDiffusion:
             if t_max > sigma_pred_threshold:
                 cur_style, cur_refine = "base", False
             eps_out, es = self._nlc_step(xt, ts_host[0], sigs[0], prev_arg, cur_style, bool(norm_eps), cur_refine,
-                                         per_sample=per_sample, prev_is_ratio=ratio)
+                                         per_sample=per_sample, prev_is_ratio=ratio, chunk_size=chunk_size)
             x0_hat, x0, x_prev, eps_used = self._sched_update(xt, eps_out, es, ind, constrain_fn, constrain_fn is not None,
                                                              return_log, noise_list)
             xt = x_prev

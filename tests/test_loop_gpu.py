@@ -23,7 +23,7 @@ def _stats(a):
     return torch.stack([a.flatten(2).mean(-1), a.flatten(2).abs().mean(-1)], dim=-1)
 
 
-def run_hip_loop(g, dtype=torch.float32, return_log=True, graphs=False, matmul="native"):
+def run_hip_loop(g, dtype=torch.float32, return_log=True, graphs=False, matmul="native", chunk_size=1):
     from diffusion_nlc_amd.experiments import ImageExperiment
     from diffusion_nlc_amd.schedulers import get_sampler
     c = g["cfg"]
@@ -41,9 +41,22 @@ def run_hip_loop(g, dtype=torch.float32, return_log=True, graphs=False, matmul="
     noises = [torch.randn(shape, generator=ng) for _ in range(int(g["n_noise"]))] or None
     gen = exp.new_gen()                       # same seed -> the same z the reference drew
     x, logs = exp.denoise_loop(shape=shape, gen=gen, style=c["style"], norm_eps=c["norm_eps"],
-                               refine_prior_sigma=c["refine"], return_log=return_log, chunk_size=1,
+                               refine_prior_sigma=c["refine"], return_log=return_log, chunk_size=chunk_size,
                                sigma_pred_threshold=c["threshold"], noise_list=noises)
     return x, logs
+
+
+def test_chunk_size_microbatches_the_eps_network():
+    """``chunk_size`` (src/experiments.py:436-450): the eps network is evaluated on len(xt) // chunk_size samples at a time - a
+    memory knob upstream.  No op of the path couples samples; what can differ is the kernel the dispatch picks for the smaller
+    launch (tile counts decide), i.e. the order of f32 additions: the f32 sample agrees with the unchunked one to 1e-4 (and with the
+    reference golden to the usual 1e-3), and a chunked run replayed from captured graphs equals the chunked eager run bit for bit."""
+    g = load_npz("loop_adm_dynamic")
+    a, _ = run_hip_loop(g, return_log=False, chunk_size=1)
+    b, _ = run_hip_loop(g, return_log=False, chunk_size=2)
+    c, _ = run_hip_loop(g, return_log=False, chunk_size=2, graphs=True)
+    assert max_err(a, b) < 1e-4 and max_err(b, g["x"]) < 1e-3
+    assert torch.equal(b, c)
 
 
 @pytest.mark.parametrize("matmul", ["native", "f16x3"])
