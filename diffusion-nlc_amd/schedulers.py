@@ -199,46 +199,52 @@ class Scheduler:
             x_n = ops.lincomb_rows(x_0, alpha.sqrt().to(dev).contiguous(), noise, (1 - alpha).sqrt().to(dev).contiguous())
         return x_n, noise
 
+    # ---- sampling ladders (src/schedulers.py:227-284) ----------------------------------------------------------------------
+    # One builder per sigma style: each returns (timesteps or None, sigmas).  The arithmetic inside them keeps the reference's
+    # operation order and dtypes (numpy float64 for the "Linear" / "Scaled" ladders, python floats for "EDM", table lookups for
+    # "DDIM") because the resulting tables are compared bit for bit with the reference's (tests/golden/sched.npz).
+    def _ladder_ddim(self, start, end, n, scale, dtype):
+        lo, hi = self.get_t_from_sigma(end).item(), self.get_t_from_sigma(start).item()
+        picked = sorted(space_timesteps(num_timesteps=hi + 1 - lo, section_counts=str(n)), reverse=True)
+        t = torch.tensor(lo + np.array(picked), dtype=dtype)
+        return t, self.get_sigma(t)
+
+    def _ladder_edm(self, start, end, n, scale, dtype, rho=7):
+        a, b = start ** (1 / rho), end ** (1 / rho)
+        return None, torch.tensor([(a + i / (n - 1) * (b - a)) ** rho for i in range(n)])
+
+    def _ladder_linear(self, start, end, n, scale, dtype):
+        return None, torch.tensor(np.exp(np.linspace(np.log(start), np.log(end), n)))
+
+    def _ladder_scaled(self, start, end, n, scale, dtype):
+        steps = np.cumsum(scale ** np.arange(n - 1))                       # geometric step lengths in log sigma
+        logs = np.log(start) + (np.log(end) - np.log(start)) / steps[-1] * steps
+        return None, torch.tensor(np.exp(np.insert(logs, 0, np.log(start))))
+
+    _LADDERS = {"DDIM": _ladder_ddim, "EDM": _ladder_edm, "Linear": _ladder_linear, "Scaled": _ladder_scaled}
+
     def set_timesteps_sigma(self, start, end, num_inference_steps, style="DDIM", scale=1, continuous_t=False):
-        """src/schedulers.py:227-284"""
+        """The sampling schedule: ``timesteps`` / ``sampling_sigmas`` (+ the terminal (-1, final_sigma) pair when set_alpha_to_one)
+        and ``min_var_coef`` from the last real step (src/schedulers.py:227-284)."""
+        if style not in self._LADDERS:
+            raise ValueError("Invalid style!")
         self.continuous_t = continuous_t
         self.num_inference_steps = num_inference_steps
-        dtype = torch.long if not continuous_t else torch.float32
-        if not self.set_alpha_to_one:
-            num_inference_steps = num_inference_steps + 1
-        if style == "DDIM":
-            start_t = self.get_t_from_sigma(start).item()
-            end_t = self.get_t_from_sigma(end).item()
-            ts = space_timesteps(num_timesteps=start_t + 1 - end_t, section_counts=str(num_inference_steps))
-            self.timesteps = torch.tensor(end_t + np.array(sorted(ts, reverse=True)), dtype=dtype)
-            sigmas = self.get_sigma(self.timesteps)
-        elif style == "EDM":
-            rho, n = 7, num_inference_steps
-            sigmas = torch.tensor([(start ** (1 / rho) + i / (n - 1) * (end ** (1 / rho) - start ** (1 / rho))) ** rho for i in range(n)])
-            self.timesteps = self.get_t_from_sigma(sigmas)
-        elif style == "Linear":
-            sigmas = torch.tensor(np.exp(np.linspace(np.log(start), np.log(end), num_inference_steps)))
-            self.timesteps = self.get_t_from_sigma(sigmas)
-        elif style == "Scaled":
-            diff = np.log(end) - np.log(start)
-            cs = np.cumsum(scale ** np.arange(num_inference_steps - 1))
-            sigmas = torch.tensor(np.exp(np.insert(np.log(start) + diff / cs[-1] * cs, 0, np.log(start))))
-            self.timesteps = self.get_t_from_sigma(sigmas)
-        else:
-            raise ValueError("Invalid style!")
-        self.timesteps = self.timesteps.squeeze()
-        sigmas = sigmas.squeeze()
-        if not continuous_t:
-            self.timesteps = replace_duplicate_t(self.timesteps)
-            self.sampling_sigmas = self.get_sigma(self.timesteps)
-        else:
-            self.sampling_sigmas = sigmas
+        n = num_inference_steps + (0 if self.set_alpha_to_one else 1)
+        t, sigmas = self._LADDERS[style](self, start, end, n, scale, torch.float32 if continuous_t else torch.long)
+        if t is None:
+            t = self.get_t_from_sigma(sigmas)
+        t, sigmas = t.squeeze(), sigmas.squeeze()
+        if not continuous_t:                                               # integer steps: de-duplicate, then sigma is the table's
+            t = replace_duplicate_t(t)
+            sigmas = self.get_sigma(t)
         if self.set_alpha_to_one:
-            self.timesteps = torch.cat([self.timesteps, torch.tensor([-1])])
-            self.sampling_sigmas = torch.cat([self.sampling_sigmas, torch.tensor([self.final_sigma])])
-        st, sp = self.sampling_sigmas[-3], self.sampling_sigmas[-2]
-        beta_t = (st ** 2 - sp ** 2) / (st ** 2 + 1)
-        self.min_var_coef = beta_t * (1 - 1 / (sp ** 2 + 1)) / (1 - 1 / (st ** 2 + 1))
+            t = torch.cat([t, torch.tensor([-1])])
+            sigmas = torch.cat([sigmas, torch.tensor([self.final_sigma])])
+        self.timesteps, self.sampling_sigmas = t, sigmas
+        s_t, s_p = sigmas[-3], sigmas[-2]                                  # the last step that ends at a real noise level
+        beta = (s_t ** 2 - s_p ** 2) / (s_t ** 2 + 1)
+        self.min_var_coef = beta * (1 - 1 / (s_p ** 2 + 1)) / (1 - 1 / (s_t ** 2 + 1))
 
     # ---- per-step algebra -------------------------------------------------------------------
     def get_eps_logvar(self, sigma_t, sigma_prev, learned_logvar=None):

@@ -188,3 +188,34 @@ def test_edm_get_args_matches_reference(cfg, tmp_path, monkeypatch):
         assert k in got and got[k] == v and type(got[k]) is type(v), (k, got.get(k), v)
     assert vars(config.model) == want["model"]
     assert (config.data.channels, config.data.image_size) == (3, 32)
+
+
+def test_product_schedule_tables_match_reference():
+    """diffusion_nlc_amd.schedulers (host tables, what every GPU loop consumes) bit for bit against the reference's tables
+    (tests/golden/sched.npz): the three DDIM ladders of the BASELINE configs, the other beta schedules, set_alpha_to_one = False,
+    the sigma -> t lookup grid; and the "EDM" / "Scaled" / "Linear" ladders (no reference fixture) against the oracle's restatement
+    of src/schedulers.py:227-284, which the same fixture file pins."""
+    from diffusion_nlc_amd.schedulers import get_sampler
+    from oracle.sched import get_sampler as oracle_sampler
+    from tests.util import load_npz
+    g = load_npz("sched")
+    for steps in (10, 50, 100):
+        s = get_sampler("ddim", 1000, steps, sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall")
+        assert torch.equal(s.timesteps, g[f"timesteps_{steps}"]) and torch.equal(s.sampling_sigmas, g[f"sampling_sigmas_{steps}"])
+        assert torch.equal(torch.as_tensor(s.min_var_coef), torch.as_tensor(g[f"min_var_coef_{steps}"]))
+    assert torch.equal(s.sigmas, g["sigmas"]) and torch.equal(s.alphas_cumprod, g["alphas_cumprod"])
+    assert torch.equal(s.get_t_from_sigma(g["t_grid_sigma"]), g["t_grid_t"])
+    for sched in ("quadratic", "cosine", "sigmoid"):
+        s2 = get_sampler("ddim", 1000, 20, beta_schedule=sched, sigma_style="DDIM", start_sigma=0, end_sigma=0)
+        assert torch.equal(s2.sigmas, g[f"sigmas_{sched}"]) and torch.equal(s2.timesteps, g[f"timesteps_{sched}"])
+    s3 = get_sampler("ddim", 1000, 10, sigma_style="DDIM", start_sigma=100, end_sigma=0, set_alpha_to_one=False)
+    assert torch.equal(s3.timesteps, g["timesteps_noalpha1"]) and torch.equal(s3.sampling_sigmas, g["sampling_sigmas_noalpha1"])
+    for style, kw in (("EDM", {}), ("Scaled", dict(linear_scale=0.9)), ("Linear", {}), ("Scaled", dict(linear_scale=1.1, continuous_t=True)),
+                      ("EDM", dict(continuous_t=True))):
+        a = get_sampler("ddim", 1000, 12, sigma_style=style, start_sigma=80, end_sigma=0.02, sampler_var="fixedsmall", **kw)
+        b = oracle_sampler("ddim", 1000, 12, sigma_style=style, start_sigma=80, end_sigma=0.02, sampler_var="fixedsmall", **kw)
+        assert a.timesteps.dtype == b.timesteps.dtype and torch.equal(a.timesteps, b.timesteps), (style, kw)
+        assert a.sampling_sigmas.dtype == b.sampling_sigmas.dtype and torch.equal(a.sampling_sigmas, b.sampling_sigmas), (style, kw)
+        assert torch.equal(torch.as_tensor(a.min_var_coef), torch.as_tensor(b.min_var_coef)), (style, kw)
+    with pytest.raises(ValueError):
+        get_sampler("ddim", 1000, 12, sigma_style="Cosine", start_sigma=80, end_sigma=0.02)
