@@ -5,7 +5,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
 out="$here/../libnlc_hip.so"
 mkdir -p "$here/obj"
-srcs="abi pack conv_igemm conv_fast conv_halo conv_narrow groupnorm attention elementwise sampler edm constraint"
+srcs="abi pack conv_igemm conv_fast conv_halo conv_narrow conv_pw groupnorm attention elementwise sampler edm constraint"
 # objects of sources that no longer exist would be linked in: drop them
 for o in "$here"/obj/*.o; do
   [ -e "$o" ] || continue

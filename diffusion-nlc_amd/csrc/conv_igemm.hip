@@ -424,6 +424,8 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         if (rc != NLC_EUNSUPPORTED) return rc;
         p.ksplit = 1; p.partial = nullptr;
         if (!Pfast) p.stats = nullptr;
+        rc = nlc_conv_pw_dispatch(p, dtype, (hipStream_t)stream);         // 1x1 with >= 1024 tiles: the persistent pointwise kernel
+        if (rc != NLC_EUNSUPPORTED) return rc;
         if (d->workspace) {                          // split-K needs [ksplit][M][Cout] f32 of caller workspace
             const int ks = nlc_conv_fast_ksplit(p, dtype);
             if (ks > 1 && d->workspace_bytes >= nlc_conv_fast_split_bytes(p, ks)) {

@@ -175,6 +175,9 @@ int nlc_conv_halo_plain_ok(const KParams& p, int dtype);          // the un-spli
 int nlc_conv_fast_stats_partials(const KParams& p, int dtype);
 // conv_halo.hip: partials per image the halo kernel would emit GroupNorm statistics with for this launch (0: it would not)
 int nlc_conv_halo_stats_partials(const KParams& p, int dtype);
+// conv_pw.hip: persistent pointwise (1x1) kernel for launches with many tiles; same return convention as the dispatchers below
+int nlc_conv_pw_ok(const KParams& p, int dtype);
+int nlc_conv_pw_dispatch(const KParams& p, int dtype, hipStream_t stream);
 // conv_narrow.hip: 3x3 with at most 16 output channels (the networks' last layer)
 int nlc_conv_narrow_ok(const KParams& p, int dtype);
 int nlc_conv_narrow_dispatch(const KParams& p, int dtype, hipStream_t stream);

@@ -1141,3 +1141,62 @@ def test_halo_and_fast_kernels_agree_to_f32_rounding(shape, t16):
     scale = sa[..., 1].abs().max()
     assert (sa[..., 0] - sc[..., 0]).abs().max() <= 2e-3 * sa[..., 0].abs().max().clamp_min(1.0)
     assert (sa[..., 1] - sc[..., 1]).abs().max() <= 2e-3 * scale
+
+
+PW_CASES = [
+    # persistent pointwise kernel (conv_pw.hip): 1x1 launches with >= 2048 (128 px x 128 ch) tiles
+    dict(B=4, C0=128, C1=64, H=128, W=128, Cout=512, res=True, scale=0.5 ** 0.5),     # tiles inside one image: one statistics atomic per wave
+    dict(B=3, C0=64, C1=0, H=148, W=148, Cout=512, res=False, scale=1.0),            # partial last pixel tile, tiles straddle images
+    dict(B=16, C0=256, C1=0, H=64, W=64, Cout=512, res=True, scale=1.0, bias=False),
+    dict(B=4, C0=128, C1=128, H=256, W=256, Cout=128, res=False, scale=1.0),         # one N-tile, 4 k-steps
+]
+
+
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_pointwise_persistent_kernel(case, t16):
+    """conv_pw_kernel (ring of three LDS stages across tile boundaries, counted waits behind the epilogue's stores and atomics):
+    against the f32 reference on the rounded operands, against conv_fast on the same launch (tuning bit 15 = never take the pointwise
+    kernel) to one storage rounding, ride-along statistics against the stored values - and a second launch bit-identical to the
+    first (a counted wait that under-waits would read a stage before its DMA landed)."""
+    from diffusion_nlc_amd import ops
+    B, C0, C1, H, W, Cout = (case[k] for k in ("B", "C0", "C1", "H", "W", "Cout"))
+    g = torch.Generator().manual_seed(_seed(case))
+    Cin = C0 + C1
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g) * 0.2 if case.get("bias", True) else None
+    res = torch.randn(B, Cout, H, W, generator=g) if case["res"] else None
+    ref = F.conv2d(_rt(x, t16), _rt(w, t16), b)
+    if res is not None:
+        ref = ref + _rt(res, t16)
+    ref = ref * case["scale"]
+    xs = _nhwc(x, t16)
+    x0, x1 = (xs[..., :C0].contiguous(), xs[..., C0:].contiguous()) if C1 else (xs, None)
+    pw = ops.pack_conv(w, b, t16, _dev())
+    rs = None if res is None else _nhwc(res, t16)
+    tiles = -(-B * H * W // 128) * (Cout // 128)
+    assert tiles >= 2048, "the case must reach the pointwise kernel"
+    outs = []
+    for tuning in (0, 0, 32768):
+        ops.CONV_TUNING = tuning
+        try:
+            y = ops.conv2d(x0, pw, x1=x1, res=rs, out_scale=case["scale"])
+        finally:
+            ops.CONV_TUNING = 0
+        outs.append((y, ops.ride_stats(y)))
+    torch.cuda.synchronize()
+    (ya, sa), (yb, sb), (yc, sc_) = outs
+    assert torch.equal(ya, yb) and torch.equal(sa, sb)                      # deterministic, launch after launch
+    _close(ya.permute(0, 3, 1, 2), ref, _tol(t16), "conv2d (pointwise kernel)")
+    ulp = 2.0 ** (-7 if t16 == torch.bfloat16 else -10)
+    a, c = ya.float().cpu(), yc.float().cpu()
+    d = (a - c).abs()
+    assert (d <= ulp * torch.maximum(a.abs(), c.abs()) * 1.01 + 4e-6 * a.abs().max()).all()      # vs conv_fast: one rounding step
+    gran = ops.stats_granule(Cout)
+    assert sa is not None and sa.shape == (B, Cout // gran, 4)
+    ch = a.view(B, H * W, Cout // gran, gran).double()
+    tot = _totals(sa)
+    s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
+    assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
+    assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3
