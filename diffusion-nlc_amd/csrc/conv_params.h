@@ -115,6 +115,21 @@ struct Stat16 {
         long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4 + fr;
         atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)((fr & 1) ? lo : hi));
     }
+    // The same for a lane that holds 8 channels from n (in s[0..1], q[0..1]: add_chunk(0, .) only): 8 (per-4 granules) or 4 (one per-8
+    // chunk) accumulators per row.
+    __device__ __forceinline__ void emit_row8(long long* tot, int b, int Cout, int n, int gran, int fr) const {
+        const float v8[2] = {s[0] + s[1], q[0] + q[1]};
+        const float v4[4] = {s[0], q[0], s[1], q[1]};
+        if (fr >= (gran == 4 ? 8 : 4)) return;
+        const int vi = fr >> 1;
+        float v = gran == 4 ? v4[0] : v8[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v = (vi == k) ? (gran == 4 ? v4[k] : v8[k & 1]) : v;
+        long long hi, lo;
+        limbs(v, hi, lo);
+        long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4 + fr;
+        atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)((fr & 1) ? lo : hi));
+    }
     // one lane alone adds everything it holds (launches whose 16-pixel rows may straddle two images: never taken by the networks)
     __device__ __forceinline__ void emit_lane(long long* tot, int b, int Cout, int n, int gran) const {
         const float v8[4] = {s[0] + s[1], q[0] + q[1], s[2] + s[3], q[2] + q[3]};

@@ -14,10 +14,10 @@
 // activation k-steps are in flight the whole launch (64 KiB per CU), there is no per-tile prologue, and while one workgroup of a CU
 // is in its epilogue the other is in its k-loop.  (A first version with ONE 512-thread workgroup per CU and 256-pixel tiles had the
 // same bytes in flight and was 5-10 % SLOWER than conv_fast: its eight waves leave every barrier together, so all of them sit in the
-// epilogue at the same time with the matrix pipe idle.)  2 x 80 KiB = all 160 KiB of LDS.  The N-tiles of one pixel tile are
-// consecutive in a workgroup's range, so the second read of the activation tile comes from the XCD's L2.
+// epilogue at the same time with the matrix pipe idle.)  2 x 80 KiB = all 160 KiB of LDS.  The channel tiles of one pixel tile are
+// walked side by side by workgroups of one XCD (cowalk, below), so the activation tile leaves HBM once.
 // Supported (dispatch falls back to conv_fast otherwise): 16-bit, NHWC output, whole 128-channel N-tiles, both input segments
-// multiples of 64 channels, no embedding / activation / upsampled residual, >= 2048 tiles (static ranges: the imbalance is one tile).
+// multiples of 64 channels, no embedding / activation / upsampled residual, >= 768 tiles (static ranges: the imbalance is one tile).
 #include "common.h"
 #include "conv_params.h"
 
@@ -56,7 +56,7 @@ __device__ __forceinline__ void pw_glds16_s(unsigned voff, const void* sbase, un
 template <int N> __device__ __forceinline__ void pw_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T>
-__global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p, int tiles_total, int NTn) {
+__global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p, int tiles_total, int NTn, int cowalk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PER = 8, ES = 2, KBE = 64;
     const int tid = threadIdx.x;
@@ -67,10 +67,24 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p,
     const int nk = p.Cin_pad / KBE;
     const int HWo = p.Hout * p.Wout;
 
-    // this workgroup's contiguous tile range; tile t = (pixel tile t / NTn, channel tile t % NTn)
+    // this workgroup's tiles: t0, t0 + tstep, ... (cnt of them); tile t = (pixel tile t / NTn, channel tile t % NTn).
+    // cowalk (launches with 2..S channel tiles, S = workgroups per XCD): the NTn workgroups of a group sit in the SAME XCD (workgroup w runs on
+    // XCD w % 8), hold one channel tile each for the whole launch and walk the same contiguous range of pixel tiles side by side, so an
+    // activation tile comes from HBM once and the group's other reads of it hit that XCD's L2 while it is still there (measured before:
+    // with the channel tiles of a pixel tile visited one after the other by one workgroup, FETCH_SIZE was 2.1 x the activation bytes -
+    // 64 workgroups x 128 KiB between the two visits is twice the L2).  Otherwise: one contiguous range of tiles per workgroup.
     const int G = gridDim.x;
-    const int t0 = (int)(((int64_t)tiles_total * blockIdx.x) / G), t1 = (int)(((int64_t)tiles_total * (blockIdx.x + 1)) / G);
-    const int total = (t1 - t0) * nk;                     // k-steps of this workgroup
+    int t0, cnt, tstep;
+    if (cowalk) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = G >> 3;
+        const int nt = slot % NTn, grp = (slot / NTn) * 8 + xcd, NG = (S / NTn) * 8, MT = tiles_total / NTn;
+        const int mb = (int)(((int64_t)MT * grp) / NG), me = (int)(((int64_t)MT * (grp + 1)) / NG);
+        t0 = mb * NTn + nt; cnt = me - mb; tstep = NTn;
+    } else {
+        t0 = (int)(((int64_t)tiles_total * blockIdx.x) / G);
+        cnt = (int)(((int64_t)tiles_total * (blockIdx.x + 1)) / G) - t0; tstep = 1;
+    }
+    const int total = cnt * nk;                           // k-steps of this workgroup
     if (total <= 0) return;
 
     const int64_t wrow = (int64_t)p.Cin_pad * ES;         // bytes per packed weight row (one tap)
@@ -90,7 +104,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p,
     asm volatile("" : "+s"(x0p), "+s"(x1p), "+s"(c0w), "+s"(c1w));
     // ---- issue cursors, across tile boundaries: the activation stream runs two k-steps ahead of the compute cursor, the weight
     //      stream one
-    int at = t0, as_ = 0;                                 // tile and k-block of the next activation step to issue
+    int at = t0, as_ = 0, a_left = cnt;                   // tile and k-block of the next activation step to issue; tiles left to issue
     // this lane's 4 activation rows of that tile (clamped to M - 1: rows beyond M are fetched from the last pixel and never stored -
     // no zero page, no branch) as byte addresses of the lane's chunk in k-block 0 of each input segment: a k-step adds 128 bytes
     const char* ap0[4]; const char* ap1[4];
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p,
         const int koff = (first ? as_ : as_ - nk0) * KB_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) pw_glds16((first ? ap0[i] : ap1[i]) + koff, a_base + i * 32 * KB_BYTES);
-        if (++as_ == nk) { as_ = 0; ++at; if (at < t1) a_setup(at); }
+        if (++as_ == nk) { as_ = 0; at += tstep; if (--a_left > 0) a_setup(at); }
     };
     int bt = t0, bs = 0;                                  // tile and k-block of the next weight step to issue
     const char* bw = p.w + (int64_t)(t0 % NTn) * PW_BN * wrow;      // weight rows of that tile's channel tile (wave-uniform)
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p,
         const char* wb = bw + bs * KB_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) pw_glds16_s(woff[i], wb, b_base + i * 32 * KB_BYTES);
-        if (++bs == nk) { bs = 0; ++bt; bw = p.w + (int64_t)(bt % NTn) * PW_BN * wrow; }
+        if (++bs == nk) { bs = 0; bt += tstep; bw = p.w + (int64_t)(bt % NTn) * PW_BN * wrow; }
     };
 
     const int wm = wave >> 1, wn = wave & 1;
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p,
             const bool full = (ct / NTn) * PW_BM + PW_BM <= p.M;                  // workgroup-uniform: every lane stores its 4 rows
             epilogue(ct);
             zero_acc();
-            cs = 0; ++ct;
+            cs = 0; ct += tstep;
             // A(g+1) and B(g+1) must have landed.  Behind them this wave issued, in order: A(g+2) (if any), the epilogue's 8 row stores
             // and its statistics atomics (the epilogue's loads have completed: their values were used) - full tiles only; a partial
             // tile (the last pixel tile of a launch) drains everything
@@ -280,15 +294,272 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pw_kernel(const KParams p,
 }
 
 template <typename T>
-int launch_pw(const KParams& p, int tiles_total, int NTn, int grid, hipStream_t stream) {
+int launch_pw(const KParams& p, int tiles_total, int NTn, int grid, int cowalk, hipStream_t stream) {
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pw_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
     });
-    hipLaunchKernelGGL((conv_pw_kernel<T>), dim3(grid), dim3(PW_THREADS), PW_LDS, stream, p, tiles_total, NTn);
+    hipLaunchKernelGGL((conv_pw_kernel<T>), dim3(grid), dim3(PW_THREADS), PW_LDS, stream, p, tiles_total, NTn, cowalk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(pointwise): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Register-resident weights (K <= 512).  Counters of the kernel above on 512 -> 256 @256x256, B = 16 (tools/pw_pmc.sh,
+// profiles/r04f_pw_pmc.json): HBM is NOT the limit - 1.3 GB read at an L2-side read latency of 1 200 cycles, 40 % of the streaming
+// rate - the L2 is: busy 96 % of the launch, 50 M requests of which 33 M are 128-byte reads (the activation tile once per channel
+// tile + the SAME weight k-blocks again for every pixel tile: 4.2 GB through L2 for 1.07 GB of activations) and 17 M are 32-byte
+// writes.  Time tracks the L2 request count: activation stream alone 202 us, + stores 342, + weight stream 400, + MFMA 450.
+// Here a workgroup keeps ONE channel tile for the whole launch (the side-by-side walk above), so its weights - 32 output channels x K per
+// wave - are loaded ONCE into registers as MFMA A-operand fragments (128 VGPRs at K = 512): no weight stream, no weight fragment reads
+// from LDS, and all 80 KiB of LDS are a five-stage activation ring (4 x 16 KiB in flight per workgroup).  Tile = 64 pixels x 128
+// channels, a stage = 64 pixels x 128 input channels (256-byte row pieces, chunk index XOR-swizzled with the pixel's low 4 bits at
+// DMA time so the fragment reads of 16 pixels hit 16 different 16-byte bank groups); every wave reads the whole stage (B operand) and
+// multiplies it with its own 32 channels.  A lane ends up with 8 consecutive channels of a pixel: 16-byte stores, 64 bytes per pixel
+// and wave (half the write requests).
+constexpr int PR_BM = 64, PR_NS = 5, PR_AH = PR_NS - 1, PR_ROW = 256, PR_STAGE = PR_BM * PR_ROW, PR_LDS = PR_NS * PR_STAGE;
+
+template <typename T, int NKB>
+__global__ __launch_bounds__(PW_THREADS, 2) void conv_pwr_kernel(const KParams p, int MT, int NTn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const int HWo = p.Hout * p.Wout;
+    // group of NTn workgroups in one XCD, one channel tile each, the same pixel tiles side by side (conv_pw_kernel, cowalk)
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = G >> 3;
+    const int nt = slot % NTn, grp = (slot / NTn) * 8 + xcd, NG = (S / NTn) * 8;
+    const int mb = (int)(((int64_t)MT * grp) / NG), cnt = (int)(((int64_t)MT * (grp + 1)) / NG) - mb;
+    if (cnt <= 0) return;
+    const int total = cnt * NKB;
+    const int n0 = nt * PW_BN + wave * 32;                 // this wave's 32 output channels
+
+    // ---- weights: lane (fr, fq) holds, for channel block jb and 32-wide k slice q, k = 32 q + 8 fq ... + 7 of output channel
+    //      n0 + (fr >> 2) * 8 + jb * 4 + (fr & 3) - the row permutation that leaves a lane with 8 consecutive channels of D
+    uint4 wr[NKB][4][2];
+    {
+        const int64_t wrow = (int64_t)p.Cin_pad * 2;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const char* wp = p.w + (int64_t)(n0 + (fr >> 2) * 8 + jb * 4 + (fr & 3)) * wrow + fq * 16;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) wr[kb][kk][jb] = *reinterpret_cast<const uint4*>(wp + (kb * 4 + kk) * 64);
+        }
+    }
+    float cb[8];
+    {
+        const int n = n0 + fq * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cb[k] = p.bias ? p.bias[n + k] : 0.f;
+    }
+    // Everything loaded so far is consumed HERE, in front of the loop: the compiler's wait-count pass would otherwise put its
+    // s_waitcnt vmcnt(0) for these loads in front of their first use INSIDE the loop, where it drains the DMA ring at every step.
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+                asm volatile("" : "+v"(wr[kb][kk][jb].x), "+v"(wr[kb][kk][jb].y), "+v"(wr[kb][kk][jb].z), "+v"(wr[kb][kk][jb].w));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(cb[k]));
+
+    const char* x0p = p.x0; const char* x1p = p.x1;
+    int c0w = p.C0, c1w = p.C1;
+    asm volatile("" : "+s"(x0p), "+s"(x1p), "+s"(c0w), "+s"(c1w));
+    const int nk0 = c0w >> 7;                              // 128-channel blocks of the first segment
+    // ---- DMA: wave-instruction i of wave w fills LDS rows (pixels) (4 i + w) * 4 + (lane >> 4), 16 lanes per 256-byte row; the lane
+    //      in chunk slot (lane & 15) fetches global chunk slot ^ (row & 15); (row & 15) = 4 w + (lane >> 4) for every i
+    const int dr = wave * 4 + (lane >> 4);
+    const int gch = (lane & 15) ^ dr;
+    unsigned ao0[4], ao1[4];                               // byte offsets of this lane's 4 rows of the tile in k-block 0 of each segment
+    auto a_setup = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = min(mt * PR_BM + i * 16 + dr, p.M - 1);      // rows beyond M: the last pixel, never stored
+            ao0[i] = (unsigned)((m * c0w + gch * 8) * 2);
+            ao1[i] = (unsigned)((m * c1w + gch * 8) * 2);
+        }
+    };
+    int at = mb, as_ = 0, a_left = cnt;
+    auto issue = [&](int stage) {
+        const unsigned base = lds0 + stage * PR_STAGE + wave * 4 * PR_ROW;
+        const bool first = as_ < nk0;                      // wave-uniform
+        const unsigned koff = (unsigned)((first ? as_ : as_ - nk0) * PR_ROW);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pw_glds16_s((first ? ao0[i] : ao1[i]) + koff, first ? x0p : x1p, base + i * 16 * PR_ROW);
+        if (++as_ == NKB) { as_ = 0; ++at; if (--a_left > 0) a_setup(at); }
+    };
+
+    f32x4_t acc[4][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    };
+    auto row16_sum = [](float x) {
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));
+        return x;
+    };
+    const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+    const bool whole = (HWo % PR_BM) == 0;
+    const float sc = p.out_scale;
+    // ---- epilogue: lane (fr, fq) holds, for the 4 pixels m0 + 16 pb + fr, channels n0 + 8 fq + [0, 8): per wave exactly 4 row
+    //      stores (full tiles) + 1 or 4 statistics atomics
+    auto epilogue = [&](int mt) {
+        const int m0 = mt * PR_BM, n = n0 + fq * 8;
+        uint4 rq[4], pk[4];
+        if (has_res) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const int m = min(m0 + pb * 16 + fr, p.M - 1);
+                rq[pb] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + (int64_t)m * p.Cout + n);
+            }
+        }
+        Stat16 st;
+        st.zero();
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            float v[8];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[jb * 4 + r] = acc[pb][jb][r] + cb[jb * 4 + r];
+            if (has_res) {
+                float rr[8];
+                chunk_to_f32<T>(rq[pb], rr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += rr[k];
+            }
+            if (sc != 1.0f) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= sc;
+            }
+            pk[pb] = f32_to_chunk<T>(v);
+            if (has_stats) {
+                const int m = m0 + pb * 16;
+                if (!whole) st.zero();
+                if (m < p.M) st.add_chunk<T>(0, pk[pb]);
+                if (!whole) {
+                    st.s[0] = row16_sum(st.s[0]); st.s[1] = row16_sum(st.s[1]); st.q[0] = row16_sum(st.q[0]); st.q[1] = row16_sum(st.q[1]);
+                    if (m < p.M) st.emit_row8(p.stats, p.div_hwo.div(m), p.Cout, n, p.stats_gran, fr);
+                }
+            }
+        }
+        if (has_stats && whole) {
+            st.s[0] = row16_sum(st.s[0]); st.s[1] = row16_sum(st.s[1]); st.q[0] = row16_sum(st.q[0]); st.q[1] = row16_sum(st.q[1]);
+            st.emit_row8(p.stats, m0 / HWo, p.Cout, n, p.stats_gran, fr);
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const int m = m0 + pb * 16 + fr;
+            if (m >= p.M) continue;
+            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (int64_t)m * p.Cout + n) = pk[pb];
+        }
+    };
+
+    // ---- prologue: PR_AH stages in flight, stage 0 landed
+    a_setup(mb);
+    if (total >= PR_AH) {
+#pragma unroll
+        for (int d = 0; d < PR_AH; ++d) issue(d);
+        pw_wait<PW_PCS * (PR_AH - 1)>();
+    } else {
+        for (int d = 0; d < total; ++d) issue(d);
+        pw_wait<0>();
+    }
+    __syncthreads();
+    zero_acc();
+    int stage = 0, g = 0;
+    for (int ti = 0; ti < cnt; ++ti) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb, ++g) {
+            const bool more = g + PR_AH < total;           // workgroup-uniform
+            // the stage read during step g - 1 (every wave is past that step's barrier) receives step g + PR_AH
+            if (more) issue(stage == 0 ? PR_NS - 1 : stage - 1);
+            const char* As = smem + stage * PR_STAGE;
+            // fragments of k slice kk + 1 are requested before the 8 MFMAs of slice kk (pinned: left alone the compiler reads two
+            // fragments, waits, multiplies, reads two more - the LDS round trip in line with the matrix pipe)
+            uint4 f[2][4];
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) f[0][pb] = *reinterpret_cast<const uint4*>(As + (pb * 16 + fr) * PR_ROW + ((fq ^ fr) << 4));
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 3) {
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb)
+                        f[(kk + 1) & 1][pb] = *reinterpret_cast<const uint4*>(As + (pb * 16 + fr) * PR_ROW + ((((kk + 1) * 4 + fq) ^ fr) << 4));
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                }
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    Mfma16<T>::run(wr[kb][kk][0], f[kk & 1][pb], acc[pb][0]);      // D[channel][pixel]
+                    Mfma16<T>::run(wr[kb][kk][1], f[kk & 1][pb], acc[pb][1]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            if (kb == NKB - 1) {
+                const bool full = (mb + ti) * PR_BM + PR_BM <= p.M;
+                epilogue(mb + ti);
+                zero_acc();
+                // step g + 1 must have landed; behind it this wave issued steps g + 2 .. g + PR_AH, then the 4 row stores and the
+                // statistics atomics (full tiles; a partial tile - the last of a launch - drains everything)
+                if (full && more) {
+                    if (!has_stats) pw_wait<PW_PCS * (PR_AH - 1) + 4>();
+                    else if (whole) pw_wait<PW_PCS * (PR_AH - 1) + 4 + 1>();
+                    else pw_wait<PW_PCS * (PR_AH - 1) + 4 + 4>();
+                } else {
+                    pw_wait<0>();
+                }
+            } else {
+                if (more) pw_wait<PW_PCS * (PR_AH - 1)>(); else pw_wait<0>();
+            }
+            __syncthreads();
+            if (++stage == PR_NS) stage = 0;
+        }
+    }
+}
+
+template <typename T, int NKB>
+int launch_pwr(const KParams& p, int MT, int NTn, int grid, hipStream_t stream) {
+    static DeviceOnce once;
+    (void)nlc_device_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwr_kernel<T, NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS);
+    });
+    hipLaunchKernelGGL((conv_pwr_kernel<T, NKB>), dim3(grid), dim3(PW_THREADS), PR_LDS, stream, p, MT, NTn);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { nlc_set_error("nlc_conv2d(pointwise, resident weights): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
+    return NLC_OK;
+}
+template <typename T>
+int launch_pwr_k(const KParams& p, int MT, int NTn, int grid, hipStream_t stream) {
+    switch (p.Cin_pad / 128) {
+        case 1: return launch_pwr<T, 1>(p, MT, NTn, grid, stream);
+        case 2: return launch_pwr<T, 2>(p, MT, NTn, grid, stream);
+        case 3: return launch_pwr<T, 3>(p, MT, NTn, grid, stream);
+        default: return launch_pwr<T, 4>(p, MT, NTn, grid, stream);
+    }
+}
+
+// the resident-weights form: K <= 512 in whole 128-channel blocks per segment, whole groups of channel tiles per XCD, 32-bit offsets
+bool pwr_ok(const KParams& p, int grid) {
+    if (p.tuning & 65536) return false;                                         // tuning bit 16: never (A/B against the streaming form)
+    if ((p.C0 & 127) != 0 || (p.C1 & 127) != 0 || p.Cin_pad > 512) return false;
+    // every workgroup first loads its channel tile's weights (128 KiB from L2): launches of fewer than ~1 500 tiles stay with the streaming
+    // form (512 -> 256 @64x64, B = 16, 1 024 tiles: 31.1 us streaming, 34.9 resident, 35.0 conv_fast; 256 -> 512 @16x16, B = 200, 1 600: 34.4 / 32.0 / 38.6)
+    if ((int64_t)cdiv(p.M, PW_BM) * (p.Cout / PW_BN) < 1536) return false;
+    const int NTn = p.Cout / PW_BN, S = grid >> 3;
+    if ((grid & 7) != 0 || S < NTn || (S % NTn) != 0) return false;
+    if ((int64_t)p.M * p.C0 * 2 >= (1ll << 32) || (int64_t)p.M * p.C1 * 2 >= (1ll << 32)) return false;
+    return true;
 }
 
 }  // namespace
@@ -307,7 +578,7 @@ int nlc_conv_pw_ok(const KParams& p, int dtype) {
     if (p.Cin_pad > 768) return 0;        // longer K: the launch is matrix-bound, not latency-bound, and conv_fast's leaner k-loop wins
                                           // (1024 -> 512 @64x64, B = 16: 99 vs 92 us)
     const int64_t tiles = (int64_t)cdiv(p.M, PW_BM) * (p.Cout / PW_BN);
-    return tiles >= 2048 ? 1 : 0;                                               // static tile ranges: >= 4 tiles per workgroup
+    return tiles >= 768 ? 1 : 0;          // static tile ranges; below, conv_fast's one-tile workgroups are level or ahead (32x32, B = 16: 24 us both)
 }
 
 int nlc_conv_pw_dispatch(const KParams& p, int dtype, hipStream_t stream) {
@@ -317,6 +588,13 @@ int nlc_conv_pw_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     const int NTn = p.Cout / PW_BN;
     const int tiles = cdiv(p.M, PW_BM) * NTn;
     const int grid = tiles < 2 * ncu ? tiles : 2 * ncu;                         // two persistent workgroups per CU
-    if (dtype == NLC_BF16) return launch_pw<bf16_raw>(p, tiles, NTn, grid, stream);
-    return launch_pw<f16_raw>(p, tiles, NTn, grid, stream);
+    if (pwr_ok(p, grid)) {
+        const int MT = cdiv(p.M, PR_BM);
+        return dtype == NLC_BF16 ? launch_pwr_k<bf16_raw>(p, MT, NTn, grid, stream) : launch_pwr_k<f16_raw>(p, MT, NTn, grid, stream);
+    }
+    // side-by-side walk of the channel tiles (kernel comment): whole groups of NTn workgroups per XCD; tuning bit 17 = never (A/B)
+    const int S = grid >> 3;
+    const int cowalk = (NTn > 1 && (grid & 7) == 0 && S >= NTn && (S % NTn) == 0 && !(p.tuning & 131072)) ? 1 : 0;
+    if (dtype == NLC_BF16) return launch_pw<bf16_raw>(p, tiles, NTn, grid, cowalk, stream);
+    return launch_pw<f16_raw>(p, tiles, NTn, grid, cowalk, stream);
 }

@@ -1144,11 +1144,17 @@ def test_halo_and_fast_kernels_agree_to_f32_rounding(shape, t16):
 
 
 PW_CASES = [
-    # persistent pointwise kernel (conv_pw.hip): 1x1 launches with >= 2048 (128 px x 128 ch) tiles
+    # persistent pointwise kernel (conv_pw.hip): 1x1 launches with >= 768 (128 px x 128 ch) tiles
     dict(B=4, C0=128, C1=64, H=128, W=128, Cout=512, res=True, scale=0.5 ** 0.5),     # tiles inside one image: one statistics atomic per wave
     dict(B=3, C0=64, C1=0, H=148, W=148, Cout=512, res=False, scale=1.0),            # partial last pixel tile, tiles straddle images
     dict(B=16, C0=256, C1=0, H=64, W=64, Cout=512, res=True, scale=1.0, bias=False),
     dict(B=4, C0=128, C1=128, H=256, W=256, Cout=128, res=False, scale=1.0),         # one N-tile, 4 k-steps
+    # ... of which the register-resident-weights form (conv_pwr_kernel) takes K <= 512 in whole 128-channel blocks per segment:
+    dict(B=2, C0=256, C1=256, H=256, W=256, Cout=256, res=False, scale=1.0),         # K = 512 over both segments, two channel tiles side by side
+    dict(B=16, C0=384, C1=0, H=128, W=128, Cout=128, res=True, scale=1.0),           # K = 384
+    dict(B=3, C0=128, C1=0, H=148, W=148, Cout=512, res=False, scale=0.5 ** 0.5),    # partial last 64-pixel tile, tiles straddle images
+    dict(B=8, C0=128, C1=0, H=256, W=256, Cout=128, res=False, scale=1.0),           # K = 128: cfg 4's shortcut
+    dict(B=16, C0=512, C1=0, H=64, W=64, Cout=256, res=False, scale=1.0),            # 1 024 tiles: streaming form, side-by-side channel tiles
 ]
 
 
@@ -1176,9 +1182,9 @@ def test_conv2d_pointwise_persistent_kernel(case, t16):
     pw = ops.pack_conv(w, b, t16, _dev())
     rs = None if res is None else _nhwc(res, t16)
     tiles = -(-B * H * W // 128) * (Cout // 128)
-    assert tiles >= 2048, "the case must reach the pointwise kernel"
+    assert tiles >= 768, "the case must reach the pointwise kernel"
     outs = []
-    for tuning in (0, 0, 32768):
+    for tuning in (0, 0, 32768, 65536):
         ops.CONV_TUNING = tuning
         try:
             y = ops.conv2d(x0, pw, x1=x1, res=rs, out_scale=case["scale"])
@@ -1186,13 +1192,16 @@ def test_conv2d_pointwise_persistent_kernel(case, t16):
             ops.CONV_TUNING = 0
         outs.append((y, ops.ride_stats(y)))
     torch.cuda.synchronize()
-    (ya, sa), (yb, sb), (yc, sc_) = outs
+    (ya, sa), (yb, sb), (yc, sc_), (ye, se) = outs                         # tuning bit 16: the streaming form where the resident one would run
     assert torch.equal(ya, yb) and torch.equal(sa, sb)                      # deterministic, launch after launch
     _close(ya.permute(0, 3, 1, 2), ref, _tol(t16), "conv2d (pointwise kernel)")
     ulp = 2.0 ** (-7 if t16 == torch.bfloat16 else -10)
     a, c = ya.float().cpu(), yc.float().cpu()
     d = (a - c).abs()
     assert (d <= ulp * torch.maximum(a.abs(), c.abs()) * 1.01 + 4e-6 * a.abs().max()).all()      # vs conv_fast: one rounding step
+    e = ye.float().cpu()
+    assert ((a - e).abs() <= ulp * torch.maximum(a.abs(), e.abs()) * 1.01 + 4e-6 * a.abs().max()).all()
+    assert (_totals(se) - _totals(sa)).abs().max() <= 1e-3 * max(_totals(sa).abs().max().item(), 1.0)
     gran = ops.stats_granule(Cout)
     assert sa is not None and sa.shape == (B, Cout // gran, 4)
     ch = a.view(B, H * W, Cout // gran, gran).double()

@@ -16,9 +16,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 FAMILIES = ["conv_halo", "gn_apply", "conv_fast_kernel<unsigned short, 1", "conv_fast_kernel<unsigned short, 9", "conv_fast_kernel<float",
-            "conv_igemm", "splitk_reduce", "avgpool", "attn_d64", "attn_kernel", "gn_finalize", "gn_stats", "conv_first", "upsample", "quantile",
+            "conv_pw", "conv_igemm", "splitk_reduce", "avgpool", "attn_d64", "attn_kernel", "gn_finalize", "gn_stats", "conv_first", "upsample", "quantile",
             "sched_", "row_sumsq"]
-CONV = ("conv_halo", "conv_fast_kernel", "conv_igemm", "splitk_reduce")
+CONV = ("conv_halo", "conv_fast_kernel", "conv_pw", "conv_igemm", "splitk_reduce")
 
 
 def csrc_sha16():
