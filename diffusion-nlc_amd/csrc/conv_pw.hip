@@ -1,21 +1,22 @@
 // Pointwise (1x1, stride 1, unpadded) convolutions with many output tiles: the skip projections of the ResBlocks, the attention
-// qkv / proj layers, the networks' "nin" shortcuts.  They are HBM-bound GEMMs, C[M][N] = X[M][K] W[N][K]^T with short K (2 ... 12 k-blocks
-// of 64 channels), and conv_fast.hip runs them latency-bound: a workgroup keeps ONE k-step (16 KiB of activations) in flight, two
-// workgroups per CU -> 32 KiB of activation bytes in flight per CU, half of what a CU's share of HBM needs behind a ~2 us miss
-// (bandwidth-delay: 31 GB/s x 2 us = 62 KiB; MI355X_MICROARCH.md "72 KiB in flight per CU hide most of an HBM miss"): 4.3-4.4 TB/s
-// where the streaming kernels reach 5.8, plus a prologue (first DMA round trip) and an epilogue bubble per 128-pixel tile.  The
-// four-stage / one-workgroup-per-CU form of conv_fast has the bytes in flight but half the waves, and measured 40-65 % slower.
+// qkv / proj layers, the networks' "nin" shortcuts.  They are GEMMs C[M][N] = X[M][K] W[N][K]^T with short K (2 ... 12 k-blocks of 64
+// channels) that move far more bytes per flop than the 3x3 layers, and conv_fast.hip - one workgroup per 128 x 128 tile, every tile
+// with its own prologue, first DMA round trip and epilogue bubble - runs them at 3.2-4.4 TB/s of algorithmic traffic.
 //
-// This kernel: TWO persistent 256-thread workgroups per CU, each walking a contiguous range of (128 pixel x 128 channel) tiles - the
-// tile, wave layout (4 waves = 2 (M) x 2 (N), 64 px x 64 cout each), fragment layout and register-direct epilogue of conv_fast.hip
-// (weights = MFMA A operand, weight rows permuted at DMA time: a lane ends up with 16 consecutive channels of one pixel).  What
-// changes is the staging: the activation stream (HBM) runs through a ring of THREE 16-KiB LDS stages and the weight stream (L2 hits)
-// through two, by LDS-DMA with counted vmcnt waits, and both rings run straight across tile boundaries: per workgroup two
-// activation k-steps are in flight the whole launch (64 KiB per CU), there is no per-tile prologue, and while one workgroup of a CU
-// is in its epilogue the other is in its k-loop.  (A first version with ONE 512-thread workgroup per CU and 256-pixel tiles had the
-// same bytes in flight and was 5-10 % SLOWER than conv_fast: its eight waves leave every barrier together, so all of them sit in the
-// epilogue at the same time with the matrix pipe idle.)  2 x 80 KiB = all 160 KiB of LDS.  The channel tiles of one pixel tile are
-// walked side by side by workgroups of one XCD (cowalk, below), so the activation tile leaves HBM once.
+// What bounds them was measured, not assumed (profiles/r04_summary.md section 5): a pure LDS-DMA stream of the same tensor reaches
+// 6.1 TB/s in EITHER access shape (128-byte column slices of 128 pixel rows, or whole rows) with two 16-KiB stages in flight per
+// workgroup, 5.3 TB/s with the output write stream beside it (tools/dma_shape_probe.hip) - so neither the access shape nor the depth
+// of the prefetch ring is the limit; the L2 is (tools/pw_pmc.sh: busy 96 % of the launch, 50 M requests, HBM read latency a relaxed
+// 1 200 cycles): the activation tile once per channel tile, the SAME weight k-blocks again for every pixel tile, 32-byte write requests.
+// Two kernels here, both persistent, TWO 256-thread workgroups per CU (a first version with ONE 512-thread workgroup per CU and
+// 256-pixel tiles was 5-10 % SLOWER than conv_fast: its eight waves leave every barrier together, so all of them sit in the epilogue
+// at the same time), both walking the channel tiles of a pixel tile side by side in one XCD (cowalk, below):
+//  * conv_pwr_kernel (K <= 512, >= 1536 tiles): weights register-resident, all LDS a five-stage activation ring - see its comment;
+//  * conv_pw_kernel (any K <= 768, >= 768 tiles): the tile, wave layout (4 waves = 2 (M) x 2 (N), 64 px x 64 cout each), fragment
+//    layout and register-direct epilogue of conv_fast.hip (weights = MFMA A operand, weight rows permuted at DMA time: a lane ends up
+//    with 16 consecutive channels of one pixel); the activation stream runs through a ring of THREE 16-KiB LDS stages and the weight
+//    stream (L2 hits) through two, by LDS-DMA with counted vmcnt waits, and both rings run straight across tile boundaries: no per-tile
+//    prologue, and while one workgroup of a CU is in its epilogue the other is in its k-loop.  2 x 80 KiB = all 160 KiB of LDS.
 // Supported (dispatch falls back to conv_fast otherwise): 16-bit, NHWC output, whole 128-channel N-tiles, both input segments
 // multiples of 64 channels, no embedding / activation / upsampled residual, >= 768 tiles (static ranges: the imbalance is one tile).
 #include "common.h"
