@@ -48,7 +48,7 @@ template <int RB> __device__ __forceinline__ int lds_addr(int row, int c) { retu
 
 template <typename T> using AttnMma = Mfma16<T>;
 
-template <typename T, int D> struct AttnCfg {
+template <typename T, int D, bool DMA_OK = true> struct AttnCfg {
     static constexpr int ES = (int)sizeof(T);
     static constexpr int PER = 16 / ES;
     static constexpr int KVT = (D * ES <= 256) ? 64 : 32;
@@ -62,18 +62,29 @@ template <typename T, int D> struct AttnCfg {
     static constexpr bool QREG = (NKS * 4 <= 64);      // keep Q fragments in registers
     static constexpr int K_BYTES = KVT * RBK;
     static constexpr int P_BYTES = 16 * RBP;
-    static constexpr int LDS = 2 * K_BYTES + 4 * P_BYTES;
+    // K / V tiles by LDS-DMA into two stages (the next tile lands while this one is multiplied) wherever the rows are whole 256-byte
+    // multiples (the XOR swizzle of lds_addr is then an involution on the low 4 chunk bits: applied on the source side) and two stages
+    // fit.  Taken by launches of at most two workgroups per CU (launch()): with nobody else on the CU to cover a workgroup's load
+    // round trip it is 16-36 % faster (T = 256, D = 512, B = 8: 39.5 -> 32.8 us; T = 1024, D = 256, B = 16: 93.8 -> 60.0); a launch
+    // that oversubscribes the chip covers the round trips with other workgroups and is 11 % SLOWER with it (T = 256, D = 256, B = 200:
+    // 62.8 -> 69.8 us).  Four stages instead of two: level or slower (62.0 / 75.5 us on the last two) - a tile is ~3 800 cycles of one
+    // wave per SIMD issuing its VALU, LDS and MFMA work in line, not a load round trip.
+    static constexpr bool DMA = DMA_OK && RBK >= 256 && RBK <= 1024 && QREG && (4 * K_BYTES + 4 * P_BYTES) <= 160 * 1024;
+    static constexpr int NSTG = DMA ? 2 : 1;
+    static constexpr int PIECES = K_BYTES / 1024;      // 1-KiB wave-instructions per K (or V) tile
+    static constexpr int RPP = 1024 / (RBK <= 1024 ? RBK : 1024);      // rows per piece
+    static constexpr int LDS = NSTG * 2 * K_BYTES + 4 * P_BYTES;
 };
 
-template <typename T, int D>
+__device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_base);
+
+template <typename T, int D, bool DMA_OK>
 __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int B, int Tn, int H, int base2) {
-    using C = AttnCfg<T, D>;
+    using C = AttnCfg<T, D, DMA_OK>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;
-    char* Vs = smem + C::K_BYTES;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fr = lane & 15, fq = lane >> 4;
-    char* Ps = smem + 2 * C::K_BYTES + wave * C::P_BYTES;
+    char* Ps = smem + C::NSTG * 2 * C::K_BYTES + wave * C::P_BYTES;
 
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
     const int64_t tok_stride = (int64_t)3 * H * D;
@@ -101,7 +112,39 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
     constexpr int CH_PER_ROW = D / C::PER;
     constexpr int TILE_CHUNKS = C::KVT * CH_PER_ROW;
 
-    for (int kv0 = 0; kv0 < Tn; kv0 += C::KVT) {
+    // ---- DMA form: piece p = wave + 4 i of a tile is LDS bytes [1024 p, 1024 p + 1024) = rows p RPP ...; the lane in chunk slot
+    //      `slot` of row r fetches global chunk slot ^ (r & 15).  Keys beyond Tn: the last key's rows (masked to p = 0 below).
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    [[maybe_unused]] auto issue_tile = [&](int kv0, int stage) {
+        constexpr int LPR = 64 / C::RPP;                      // lanes (= 16-byte chunks) per row
+#pragma unroll
+        for (int i = 0; i < C::PIECES / 4; ++i) {
+            const int pc = __builtin_amdgcn_readfirstlane(wave) + 4 * i;
+            const int row = pc * C::RPP + lane / LPR, slot = lane % LPR;
+            int key = kv0 + row;
+            if (key >= Tn) key = Tn - 1;
+            const int64_t off = (int64_t)key * tok_stride + ((slot ^ (row & 15)) * C::PER);
+            const unsigned dst = lds0 + stage * 2 * C::K_BYTES + pc * 1024;
+            attn_glds16(kbase + off, dst);
+            attn_glds16(vbase + off, dst + C::K_BYTES);
+        }
+    };
+    if constexpr (C::DMA) {
+        // the Q fragments are consumed here: the compiler's own s_waitcnt vmcnt(0) for them would otherwise sit in front of their first
+        // use inside the loop and drain the tile in flight at every iteration
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
+        issue_tile(0, 0);
+    }
+
+    for (int kv0 = 0, tix = 0; kv0 < Tn; kv0 += C::KVT, ++tix) {
+        char* Ks = smem + (C::DMA ? (tix % C::NSTG) * 2 * C::K_BYTES : 0);
+        char* Vs = Ks + C::K_BYTES;
+        if constexpr (C::DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile tix (nothing else is in flight)
+            __syncthreads();                                    // everyone's pieces landed; everyone is done with tile tix - 1
+            if (kv0 + C::KVT < Tn) issue_tile(kv0 + C::KVT, (tix + 1) & 1);
+        } else {
         __syncthreads();     // previous tile fully consumed
         for (int e = tid; e < TILE_CHUNKS; e += NTHREADS) {
             const int row = e / CH_PER_ROW, c = e - row * CH_PER_ROW;
@@ -115,6 +158,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void attn_kernel(const T* __restrict__
             *reinterpret_cast<uint4*>(Vs + lds_addr<C::RBK>(row, c)) = vv;
         }
         __syncthreads();
+        }
         // (register double-buffering of the K / V tiles was measured slower, 125 vs 112 us at T = 1024: several
         //  workgroups per CU already hide the load latency and the extra 16 VGPRs cost occupancy)
 
@@ -539,17 +583,26 @@ int launch_d64(const void* qkv, void* out, int B, int Tn, int H, hipStream_t st)
     return launch_d64v<T, BASE2, ATTN_W, ATTN_NST, ATTN_QB>(qkv, out, B, Tn, H, st);
 }
 
-template <typename T, int D>
-int launch(const void* qkv, void* out, int B, int Tn, int H, int base2, hipStream_t st) {
-    using C = AttnCfg<T, D>;
+template <typename T, int D, bool DMA_OK>
+int launch_v(const void* qkv, void* out, int B, int Tn, int H, int base2, hipStream_t st) {
+    using C = AttnCfg<T, D, DMA_OK>;
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, D>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<T, D, DMA_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     });
     dim3 grid(cdiv(Tn, QB), H, B);
-    hipLaunchKernelGGL((attn_kernel<T, D>), grid, dim3(NTHREADS), C::LDS, st, (const T*)qkv, (T*)out, B, Tn, H, base2);
+    hipLaunchKernelGGL((attn_kernel<T, D, DMA_OK>), grid, dim3(NTHREADS), C::LDS, st, (const T*)qkv, (T*)out, B, Tn, H, base2);
     NLC_CHECK_LAUNCH("nlc_attention");
     return NLC_OK;
+}
+template <typename T, int D>
+int launch(const void* qkv, void* out, int B, int Tn, int H, int base2, hipStream_t st) {
+    if constexpr (AttnCfg<T, D, true>::DMA) {            // the double-buffered form for launches of at most two workgroups per CU (AttnCfg)
+        static DeviceOnce once;
+        const int ncu = once.ncu[nlc_device_once(once, [] {})];
+        if ((int64_t)cdiv(Tn, QB) * H * B <= 2 * ncu) return launch_v<T, D, true>(qkv, out, B, Tn, H, base2, st);
+    }
+    return launch_v<T, D, false>(qkv, out, B, Tn, H, base2, st);
 }
 
 template <typename T>

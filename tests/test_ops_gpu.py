@@ -406,6 +406,11 @@ ATTN_CASES = [
     dict(B=1, T=48, H=1, D=256), dict(B=1, T=70, H=1, D=512),
     # 64 channels per head, T a multiple of 256: bf16 takes the register-resident kernel (attn_d64_kernel)
     dict(B=2, T=512, H=3, D=64), dict(B=1, T=768, H=2, D=64, spike=True), dict(B=1, T=512, H=2, D=64, allneg=True),
+    # wide single heads over several key tiles (K / V tiles by LDS-DMA, double buffered, rows >= 256 bytes): the cfg 3 / cfg 4 shapes,
+    # a ragged last tile (keys beyond T are fetched from the last key and masked), f32 rows of 256 / 512 / 1024 bytes
+    dict(B=2, T=256, H=1, D=512), dict(B=3, T=256, H=1, D=256), dict(B=1, T=1024, H=2, D=128), dict(B=2, T=200, H=1, D=256),
+    dict(B=1, T=330, H=1, D=512), dict(B=1, T=300, H=2, D=64, spike=True),
+    dict(B=130, T=256, H=1, D=128),      # more than two workgroups per CU: the synchronous-load form of the same kernel
 ]
 
 
