@@ -68,7 +68,9 @@ template <typename T, int D, bool DMA_OK = true> struct AttnCfg {
     // round trip it is 16-36 % faster (T = 256, D = 512, B = 8: 39.5 -> 32.8 us; T = 1024, D = 256, B = 16: 93.8 -> 60.0); a launch
     // that oversubscribes the chip covers the round trips with other workgroups and is 11 % SLOWER with it (T = 256, D = 256, B = 200:
     // 62.8 -> 69.8 us).  Four stages instead of two: level or slower (62.0 / 75.5 us on the last two) - a tile is ~3 800 cycles of one
-    // wave per SIMD issuing its VALU, LDS and MFMA work in line, not a load round trip.
+    // wave per SIMD issuing its VALU, LDS and MFMA work in line, not a load round trip.  (A V-tile swizzle built so that the eight rows
+    // a 32-lane half of ds_read_b64_tr_b16 touches fall into eight different 32-byte bank groups - on paper the K swizzle used for V
+    // gives them four - measured level to 6 % slower, profiles/r04i_attn_v_swizzle_not_kept.log: not kept.)
     static constexpr bool DMA = DMA_OK && RBK >= 256 && RBK <= 1024 && QREG && (4 * K_BYTES + 4 * P_BYTES) <= 160 * 1024;
     static constexpr int NSTG = DMA ? 2 : 1;
     static constexpr int PIECES = K_BYTES / 1024;      // 1-KiB wave-instructions per K (or V) tile
