@@ -19,6 +19,7 @@
 //   * optionally the GroupNorm statistics of the output ride along (see conv_halo.hip).
 #include "common.h"
 #include "conv_params.h"
+#include <utility>
 
 namespace {
 
@@ -353,42 +354,55 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         if (!s_last) return;                                         // workgroup-uniform
         // The number of splits is a compile-time constant inside each case: the loaded registers must reach the wait below untouched
         // (no select, no copy - the compiler does not know they are still being written), so there is no "if (split exists)" here.
+        // Chunk c = (accumulator row i, round r of up to four splits): 4 x 4 ... 16 loads.  The loads of chunk c + 1 are in flight while
+        // chunk c is waited for (counted vmcnt) and added - the read-back used to be one exposed memory round trip per chunk (4 per
+        // tile at <= 4 splits, 8 above: 10 k of a 65 k-cycle launch, tools/fast_stamps.py), now about half of them.
         auto reduce = [&](auto ks_c) {
             constexpr int KS = decltype(ks_c)::value;
+            constexpr int R = (KS + 3) / 4, NC = 4 * R;
+            // (two chunks in flight = 128 + 64 accumulator registers: the one-workgroup-per-CU instantiation has them - 256 VGPRs, no
+            //  spills; the two-per-CU one is capped at 256 and spilled 4, possibly a register still being loaded into: one chunk there)
+            constexpr bool PIPE = STAGES >= 4;
+            f32x4_t t[2][4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s0 = 0; s0 < KS; s0 += 4) {                 // up to four splits' loads at a time (16 x 16 bytes in flight), adds in split order
-                    constexpr int NU = KS < 4 ? KS : 4;              // (KS = 5 ... 8: second round of KS - 4)
-                    const int nu = KS - s0 < NU ? KS - s0 : NU;      // compile-time after unrolling
-                    f32x4_t t[4][4];
+            for (int c = -1; c < NC; ++c) {                          // (every index below is a compile-time constant after unrolling)
+                int nxt = 0;                                         // loads of chunk c + 1, issued before chunk c is waited for
+                if (PIPE ? c + 1 < NC : c >= 0) {
+                    const int cn = PIPE ? c + 1 : c, i = cn / R, s0 = (cn % R) * 4, nu = KS - s0 < 4 ? KS - s0 : 4;
+                    nxt = PIPE ? nu * 4 : 0;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (u >= nu) break;
                         const float* pp = pbase(s0 + u) + i * 4 * 256;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(t[u][j]) : "v"(pp), "n"(j * 1024) : "memory");
+                            asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(t[PIPE ? (cn & 1) : 0][u][j]) : "v"(pp), "n"(j * 1024) : "memory");
                     }
-                    if (nu == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]) :: "memory");
-                    else if (nu == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]),
-                                                   "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]) :: "memory");
-                    else if (nu == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]),
-                                                   "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]),
-                                                   "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[2][2]), "+v"(t[2][3]) :: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]),
-                                      "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[2][2]), "+v"(t[2][3]),
-                                      "+v"(t[3][0]), "+v"(t[3][1]), "+v"(t[3][2]), "+v"(t[3][3]) :: "memory");
+                }
+                if (c < 0) continue;
+                const int i = c / R, s0 = (c % R) * 4, nu = KS - s0 < 4 ? KS - s0 : 4;
+                auto& q = t[PIPE ? (c & 1) : 0];
+                // (operands listed per split count: a register that no load of this chunk targets must not appear as "+v")
+                if (nu == 1) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]) : "n"(nxt) : "memory");
+                else if (nu == 2) asm volatile("s_waitcnt vmcnt(%8)" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]),
+                                               "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]) : "n"(nxt) : "memory");
+                else if (nu == 3) asm volatile("s_waitcnt vmcnt(%12)" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]),
+                                               "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]),
+                                               "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[2][2]), "+v"(q[2][3]) : "n"(nxt) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%16)" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[0][3]),
+                                  "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(q[1][3]), "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[2][2]), "+v"(q[2][3]),
+                                  "+v"(q[3][0]), "+v"(q[3][1]), "+v"(q[3][2]), "+v"(q[3][3]) : "n"(nxt) : "memory");
+                if (s0 == 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (u >= nu) break;
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                for (int u = 0; u < 4; ++u) {
+                    if (u >= nu) break;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[i][j][r] += t[u][j][r];      // split order: 0, 1, 2, ...
-                    }
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] += q[u][j][r];      // split order: 0, 1, 2, ...
                 }
             }
         };
@@ -403,7 +417,11 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         }
     }
     if (n >= p.Cout) return;
-    const bool pix_stats = p.ksplit > 1 || (HWo % BM) != 0;     // tiles may straddle images: statistics per 16-pixel row (emit_pix)
+    // Statistics per WAVE (its 64 consecutive pixels lie inside one image whenever the map is a whole multiple of 64 pixels - 8x8 maps and
+    // up, split launches included: one reduction + one atomic instruction per wave) or, on other maps, per 16-pixel row (emit_pix: four
+    // of each - what every split launch used to pay, 8x8 and 16x16 levels included)
+    const bool pix_stats = (HWo % 64) != 0;
+    const int wave_m = m0 + wm * 64;                             // first pixel of this wave (M % 64 == 0 with such maps: all or nothing)
 
     // ---- epilogue straight from registers
     const bool vec_ok = (p.Cout % PER) == 0;
@@ -500,10 +518,10 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
             // The statistics atomics go out BEFORE the row stores: they are performed at the memory side (device scope across the
             // XCDs' L2s) and take a few microseconds to retire - issued last, behind the stores, that latency was the tail of every
             // small launch (+2 ... 3 us per conv_fast launch when the statistics became atomics; the kernel cannot end before they do).
-            if (has_stats && !pix_stats) {   // dispatch guarantees: whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
+            if (has_stats && !pix_stats) {   // dispatch guarantees Cout % 128 == 0 -> no lane was skipped
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
-                st16.emit_row(p.stats, m0 / HWo, p.Cout, n, p.stats_gran, fr);
+                if (wave_m < p.M) st16.emit_row(p.stats, p.div_hwo.div(wave_m), p.Cout, n, p.stats_gran, fr);
                 stats_emitted = true;
             }
 #pragma unroll
@@ -590,10 +608,10 @@ __global__ __launch_bounds__(NTHREADS, STAGES == 2 ? 2 : 1) void conv_fast_kerne
         }
     }
     if constexpr (sizeof(T) == 2) {
-        if (p.stats && !pix_stats && !stats_emitted) {       // (general epilogue) whole tiles inside one image, Cout % 128 == 0 -> no lane was skipped
+        if (p.stats && !pix_stats && !stats_emitted) {       // (general epilogue) Cout % 128 == 0 -> no lane was skipped
 #pragma unroll
             for (int k = 0; k < 4; ++k) { st16.s[k] = row16_sum(st16.s[k]); st16.q[k] = row16_sum(st16.q[k]); }
-            st16.emit_row(p.stats, m0 / HWo, p.Cout, n, p.stats_gran, fr);
+            if (wave_m < p.M) st16.emit_row(p.stats, p.div_hwo.div(wave_m), p.Cout, n, p.stats_gran, fr);
         }
     }
 }
