@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NLC_HIP_LIB", _HERE / "libnlc_hip.so"))     # override: kernel A/B experiments only
 BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
 
-ABI_VERSION = 5                 # NLC_ABI_VERSION of include/nlc_hip.h
+ABI_VERSION = 6                 # NLC_ABI_VERSION of include/nlc_hip.h
 NLC_F32, NLC_BF16, NLC_F16 = 0, 1, 2
 MATH_NATIVE, MATH_F16X3 = 0, 1      # nlc_conv_desc.math / nlc_pack_conv_weights_ex
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -72,6 +72,7 @@ class ConvDesc(C.Structure):
         ("math", C.c_int32),
         ("debug", C.c_int32),
         ("w_scale", C.c_void_p),
+        ("norm_out", C.c_void_p),
     ]
 
 
@@ -114,6 +115,7 @@ SIGNATURES = {
     "nlc_conv2d_workspace_bytes": (C.c_int64, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_prologue_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
+    "nlc_conv2d_norm_out_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_groupnorm_coef": (C.c_int, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "nlc_conv_first_stats_partials": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),

@@ -267,7 +267,7 @@ static void fill_params(const nlc_conv_desc* d, KParams& p) {
     p.M = (int)M64; p.MT = cdiv(M64, BM); p.NT = cdiv(d->Cout, BN);
     p.ksplit = 1; p.partial = nullptr;
     p.stats = nullptr;
-    p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math; p.w_scale = d->w_scale;
+    p.gn_coef = d->gn_coef; p.gn_act = d->gn_act; p.math = d->math; p.w_scale = d->w_scale; p.norm_out = (char*)d->norm_out;
     p.policy = d->policy; p.tuning = d->tuning;
     p.stats_gran = d->stats_granule == 4 ? 4 : 8;
     p.div_hwo = FastDiv::make(d->Hout * d->Wout); p.div_wo = FastDiv::make(d->Wout);
@@ -299,11 +299,19 @@ extern "C" int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype) {
     return nlc_conv_fast_stats_partials(p, dtype);
 }
 
+extern "C" int nlc_conv2d_norm_out_supported(const nlc_conv_desc* d, int dtype) {
+    if (!desc_sane(d, dtype)) return 0;
+    KParams p{};
+    fill_params(d, p);
+    if (nlc_conv_narrow_ok(p, dtype)) return 0;
+    return nlc_conv_pw_norm_ok(p, dtype);
+}
+
 extern "C" int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype) {
     if (!desc_sane(d, dtype)) return 0;
     KParams p{};
     fill_params(d, p);
-    p.gn_coef = nullptr;                                 // "the gn_* fields themselves are not looked at"
+    p.gn_coef = nullptr; p.norm_out = nullptr;           // "the gn_* fields themselves are not looked at"
     if (nlc_conv_narrow_ok(p, dtype)) return 0;
     return nlc_conv_halo_prologue_ok(p, dtype);
 }
@@ -409,6 +417,14 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             NLC_REQUIRE((reinterpret_cast<uintptr_t>(d->stats_out) & 7) == 0, "nlc_conv2d: stats_out must be 8-byte aligned");
             p.stats = (long long*)d->stats_out;
         }
+        if (p.norm_out) {                            // pointwise launch that also writes act(GroupNorm(x)) of its input
+            NLC_REQUIRE(p.gn_coef, "nlc_conv2d: norm_out needs gn_coef (nlc_groupnorm_coef)");
+            NLC_REQUIRE((reinterpret_cast<uintptr_t>(p.norm_out) & 15) == 0, "nlc_conv2d: norm_out must be 16-byte aligned");
+            NLC_REQUIRE(nlc_conv_pw_norm_ok(p, dtype),
+                        "nlc_conv2d: norm_out given but this launch cannot write it (ask nlc_conv2d_norm_out_supported first)");
+            if (!Pfast) p.stats = nullptr;
+            return nlc_conv_pw_dispatch(p, dtype, (hipStream_t)stream);
+        }
         NLC_REQUIRE(!p.gn_coef || nlc_conv_halo_prologue_ok(p, dtype),
                     "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue (ask nlc_conv2d_prologue_supported first)");
         int rc = nlc_conv_narrow_dispatch(p, dtype, (hipStream_t)stream);
@@ -437,6 +453,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
         if (rc != NLC_EUNSUPPORTED) return rc;
         p.ksplit = 1; p.partial = nullptr;
     }
+    NLC_REQUIRE(!p.norm_out, "nlc_conv2d: norm_out given but this launch cannot write it");
     NLC_REQUIRE(!p.gn_coef, "nlc_conv2d: gn_coef given but this launch has no GroupNorm prologue");
     NLC_REQUIRE(!p.stats, "nlc_conv2d: stats_out given but the generic kernel emits no statistics");
     if (dtype == NLC_BF16) return launch<bf16_raw>(p, (hipStream_t)stream);

@@ -47,6 +47,7 @@ struct KParams {
     int policy;         // NLC_CONV_* kernel-selection policy of this call (nlc_conv_desc.policy)
     int tuning;         // A/B switches (nlc_conv_desc.tuning)
     const float* gn_coef; int gn_act;   // conv_halo (bf16) only: input = act(a x + b) applied in LDS (nlc_conv_desc.gn_coef)
+    char* norm_out;     // conv_pwr only (nlc_conv_desc.norm_out): also write act(a x + b) of the input, [M][C0 + C1]; the conv itself uses x
     int res_ups;        // res is [B][Hout/2][Wout/2][Cout]: output pixel (y, x) adds res pixel (y >> 1, x >> 1) (nlc_conv_desc.res_upsample2x)
     int math;           // NLC_MATH_* (nlc_conv_desc.math): f32 tensors only; F16X3 = weights packed as (hi, lo) f16 halves
     const float* w_scale; // F16X3: [Cout_pad] power-of-two factor of every output channel's conv sum (nlc_conv_desc.w_scale), else NULL
@@ -193,6 +194,7 @@ int nlc_conv_halo_stats_partials(const KParams& p, int dtype);
 // conv_pw.hip: persistent pointwise (1x1) kernel for launches with many tiles; same return convention as the dispatchers below
 int nlc_conv_pw_ok(const KParams& p, int dtype);
 int nlc_conv_pw_dispatch(const KParams& p, int dtype, hipStream_t stream);
+int nlc_conv_pw_norm_ok(const KParams& p, int dtype);    // 1 if the launch can write nlc_conv_desc.norm_out
 // conv_narrow.hip: 3x3 with at most 16 output channels (the networks' last layer)
 int nlc_conv_narrow_ok(const KParams& p, int dtype);
 int nlc_conv_narrow_dispatch(const KParams& p, int dtype, hipStream_t stream);

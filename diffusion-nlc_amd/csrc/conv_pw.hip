@@ -320,10 +320,22 @@ int launch_pw(const KParams& p, int tiles_total, int NTn, int grid, int cowalk, 
 // DMA time so the fragment reads of 16 pixels hit 16 different 16-byte bank groups); every wave reads the whole stage (B operand) and
 // multiplies it with its own 32 channels.  A lane ends up with 8 consecutive channels of a pixel: 16-byte stores, 64 bytes per pixel
 // and wave (half the write requests).
-constexpr int PR_BM = 64, PR_NS = 5, PR_AH = PR_NS - 1, PR_ROW = 256, PR_STAGE = PR_BM * PR_ROW, PR_LDS = PR_NS * PR_STAGE;
+//
+// NORM (nlc_conv_desc.norm_out): the ResBlock whose skip projection this is also needs act(GroupNorm(x)) of the SAME input for its first
+// 3x3 - a separate pass that reads x once more.  Here the stage that just fed the MFMAs is read from LDS a second time, normalised
+// (y = a[b][c] x + b[b][c] from the nlc_groupnorm_coef table of the tile's image, kept in 4 KiB of LDS and reloaded when the image
+// changes; + SiLU) and written to norm_out [M][C0 + C1]: thread (chunk column tid & 15, pixel row tid >> 4) handles its 8 channels of
+// pixels row, row + 16, +32, +48 - whole 256-byte row pieces per wave-instruction on both the LDS and the global side.  Of a group's
+// NTn workgroups the one with kb % NTn == nt does stage kb.  One stage less in the ring (4 x 16 + 4 KiB: two workgroups per CU).
+constexpr int PR_BM = 64, PR_ROW = 256, PR_STAGE = PR_BM * PR_ROW;
+constexpr int PR_COEF_BYTES = 4096;                       // float2 [512]
+template <bool NORM> struct PrRing {
+    static constexpr int NS = NORM ? 4 : 5, AH = NS - 1, LDS = NS * PR_STAGE + (NORM ? PR_COEF_BYTES : 0);
+};
 
-template <typename T, int NKB>
+template <typename T, int NKB, bool NORM>
 __global__ __launch_bounds__(PW_THREADS, 2) void conv_pwr_kernel(const KParams p, int MT, int NTn) {
+    constexpr int PR_NS = PrRing<NORM>::NS, PR_AH = PrRing<NORM>::AH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -466,6 +478,41 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pwr_kernel(const KParams p
         }
     };
 
+    // ---- NORM: coefficient table of the current image in LDS, and the normalisation of one stage
+    [[maybe_unused]] char* coef_s = smem + PR_NS * PR_STAGE;
+    [[maybe_unused]] int img = -1;
+    [[maybe_unused]] const int Ctot = c0w + c1w;
+    [[maybe_unused]] auto load_coefs = [&](int b) {          // workgroup-uniform; every thread moves 16 bytes (two channels)
+        __syncthreads();                                      // nobody is still reading the previous image's table
+        if (tid * 2 < Ctot) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p.gn_coef + ((int64_t)b * Ctot + tid * 2) * 2);
+            *reinterpret_cast<uint4*>(coef_s + tid * 16) = v;
+        }
+        __syncthreads();
+    };
+    [[maybe_unused]] auto normalise = [&](const char* As, int mt, int kb) {
+        const int cc = tid & 15, pr = tid >> 4;
+        const int ch = kb * 128 + cc * 8;
+        float ca[8], cb[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(coef_s + (ch + 2 * q) * 8);      // a0 b0 a1 b1
+            ca[2 * q] = v.x; cb[2 * q] = v.y; ca[2 * q + 1] = v.z; cb[2 * q + 1] = v.w;
+        }
+        const bool silu = p.gn_act == NLC_ACT_SILU;
+#pragma unroll 1                                                  // (register pressure: K = 512 holds 128 weight registers)
+        for (int i = 0; i < 4; ++i) {
+            const int row = pr + 16 * i, m = mt * PR_BM + row;
+            const uint4 xv = *reinterpret_cast<const uint4*>(As + row * PR_ROW + ((cc ^ pr) << 4));
+            float v[8];
+            chunk_to_f32<T>(xv, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = fmaf(ca[k], v[k], cb[k]); if (silu) v[k] = silu_f(v[k]); }
+            const uint4 pk = f32_to_chunk<T>(v);
+            if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.norm_out) + (int64_t)m * Ctot + ch) = pk;
+        }
+    };
+
     // ---- prologue: PR_AH stages in flight, stage 0 landed
     a_setup(mb);
     if (total >= PR_AH) {
@@ -483,12 +530,28 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pwr_kernel(const KParams p
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb, ++g) {
             const bool more = g + PR_AH < total;           // workgroup-uniform
+            if constexpr (NORM) {
+                if (kb == 0) {                              // a tile lies inside one image (dispatch: HWo % 64 == 0)
+                    const int b = p.div_hwo.div((mb + ti) * PR_BM);
+                    if (b != img) { load_coefs(b); img = b; }
+                }
+            }
             // the stage read during step g - 1 (every wave is past that step's barrier) receives step g + PR_AH
             if (more) issue(stage == 0 ? PR_NS - 1 : stage - 1);
             const char* As = smem + stage * PR_STAGE;
             // fragments of k slice kk + 1 are requested before the 8 MFMAs of slice kk (pinned: left alone the compiler reads two
             // fragments, waits, multiplies, reads two more - the LDS round trip in line with the matrix pipe)
             uint4 f[2][4];
+            if constexpr (NORM && NKB == 4) {                // (no register to spare for the second fragment set: measured level anyway)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) {
+                        const uint4 fx = *reinterpret_cast<const uint4*>(As + (pb * 16 + fr) * PR_ROW + (((kk * 4 + fq) ^ fr) << 4));
+                        Mfma16<T>::run(wr[kb][kk][0], fx, acc[pb][0]);
+                        Mfma16<T>::run(wr[kb][kk][1], fx, acc[pb][1]);
+                    }
+            } else {
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) f[0][pb] = *reinterpret_cast<const uint4*>(As + (pb * 16 + fr) * PR_ROW + ((fq ^ fr) << 4));
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -507,21 +570,35 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pwr_kernel(const KParams p
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
+            }
+            const bool full = (mb + ti) * PR_BM + PR_BM <= p.M;
+            bool mine = false;                              // workgroup-uniform: this workgroup normalises this stage (4 more stores)
+            if constexpr (NORM) {
+                mine = (kb % NTn) == nt;
+                if (mine) normalise(As, mb + ti, kb);
+            }
             if (kb == NKB - 1) {
-                const bool full = (mb + ti) * PR_BM + PR_BM <= p.M;
                 epilogue(mb + ti);
                 zero_acc();
-                // step g + 1 must have landed; behind it this wave issued steps g + 2 .. g + PR_AH, then the 4 row stores and the
-                // statistics atomics (full tiles; a partial tile - the last of a launch - drains everything)
+                // step g + 1 must have landed; behind it this wave issued steps g + 2 .. g + PR_AH, then (NORM) this stage's 4 row
+                // stores, then the 4 row stores and the statistics atomics (full tiles; a partial tile - the last of a launch - drains
+                // everything).  Older stores than step g + 1's DMA are simply waited for.
                 if (full && more) {
-                    if (!has_stats) pw_wait<PW_PCS * (PR_AH - 1) + 4>();
-                    else if (whole) pw_wait<PW_PCS * (PR_AH - 1) + 4 + 1>();
-                    else pw_wait<PW_PCS * (PR_AH - 1) + 4 + 4>();
+                    if (mine) {
+                        if (!has_stats) pw_wait<PW_PCS * (PR_AH - 1) + 8>();
+                        else if (whole) pw_wait<PW_PCS * (PR_AH - 1) + 8 + 1>();
+                        else pw_wait<PW_PCS * (PR_AH - 1) + 8 + 4>();
+                    } else {
+                        if (!has_stats) pw_wait<PW_PCS * (PR_AH - 1) + 4>();
+                        else if (whole) pw_wait<PW_PCS * (PR_AH - 1) + 4 + 1>();
+                        else pw_wait<PW_PCS * (PR_AH - 1) + 4 + 4>();
+                    }
                 } else {
                     pw_wait<0>();
                 }
             } else {
-                if (more) pw_wait<PW_PCS * (PR_AH - 1)>(); else pw_wait<0>();
+                if (more && full) { if (mine) pw_wait<PW_PCS * (PR_AH - 1) + 4>(); else pw_wait<PW_PCS * (PR_AH - 1)>(); }
+                else pw_wait<0>();
             }
             __syncthreads();
             if (++stage == PR_NS) stage = 0;
@@ -529,24 +606,33 @@ __global__ __launch_bounds__(PW_THREADS, 2) void conv_pwr_kernel(const KParams p
     }
 }
 
-template <typename T, int NKB>
+template <typename T, int NKB, bool NORM>
 int launch_pwr(const KParams& p, int MT, int NTn, int grid, hipStream_t stream) {
     static DeviceOnce once;
     (void)nlc_device_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwr_kernel<T, NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pwr_kernel<T, NKB, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PrRing<NORM>::LDS);
     });
-    hipLaunchKernelGGL((conv_pwr_kernel<T, NKB>), dim3(grid), dim3(PW_THREADS), PR_LDS, stream, p, MT, NTn);
+    hipLaunchKernelGGL((conv_pwr_kernel<T, NKB, NORM>), dim3(grid), dim3(PW_THREADS), PrRing<NORM>::LDS, stream, p, MT, NTn);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { nlc_set_error("nlc_conv2d(pointwise, resident weights): launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
     return NLC_OK;
 }
 template <typename T>
 int launch_pwr_k(const KParams& p, int MT, int NTn, int grid, hipStream_t stream) {
+    if (p.norm_out) {
+        switch (p.Cin_pad / 128) {
+            case 1: return launch_pwr<T, 1, true>(p, MT, NTn, grid, stream);
+            case 2: return launch_pwr<T, 2, true>(p, MT, NTn, grid, stream);
+            case 3: return launch_pwr<T, 3, true>(p, MT, NTn, grid, stream);
+            default: return launch_pwr<T, 4, true>(p, MT, NTn, grid, stream);
+        }
+    }
     switch (p.Cin_pad / 128) {
-        case 1: return launch_pwr<T, 1>(p, MT, NTn, grid, stream);
-        case 2: return launch_pwr<T, 2>(p, MT, NTn, grid, stream);
-        case 3: return launch_pwr<T, 3>(p, MT, NTn, grid, stream);
-        default: return launch_pwr<T, 4>(p, MT, NTn, grid, stream);
+        case 1: return launch_pwr<T, 1, false>(p, MT, NTn, grid, stream);
+        case 2: return launch_pwr<T, 2, false>(p, MT, NTn, grid, stream);
+        case 3: return launch_pwr<T, 3, false>(p, MT, NTn, grid, stream);
+        default: return launch_pwr<T, 4, false>(p, MT, NTn, grid, stream);
     }
 }
 
@@ -571,7 +657,7 @@ int nlc_conv_pw_ok(const KParams& p, int dtype) {
     if (p.policy == NLC_CONV_GENERIC) return 0;
     if (!(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && !p.ups)) return 0;
     if (p.Hout != p.Hin || p.Wout != p.Win) return 0;
-    if (p.out_mode != NLC_OUT_NHWC || p.act != NLC_ACT_NONE || p.emb || p.res_ups || p.gn_coef || p.ksplit > 1) return 0;
+    if (p.out_mode != NLC_OUT_NHWC || p.act != NLC_ACT_NONE || p.emb || p.res_ups || (p.gn_coef && !p.norm_out) || p.ksplit > 1) return 0;
     if ((p.Cout % PW_BN) != 0 || (p.C0 % 64) != 0 || (p.C1 % 64) != 0 || p.Cin_pad != p.C0 + p.C1) return 0;
     if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) != 0) return 0;
     const int HWo = p.Hout * p.Wout;
@@ -582,8 +668,26 @@ int nlc_conv_pw_ok(const KParams& p, int dtype) {
     return tiles >= 768 ? 1 : 0;          // static tile ranges; below, conv_fast's one-tile workgroups are level or ahead (32x32, B = 16: 24 us both)
 }
 
+static int pw_grid(const KParams& p) {
+    static DeviceOnce once;
+    const int ncu = once.ncu[nlc_device_once(once, [] {})];
+    const int tiles = cdiv(p.M, PW_BM) * (p.Cout / PW_BN);
+    return tiles < 2 * ncu ? tiles : 2 * ncu;                                   // two persistent workgroups per CU
+}
+
+// nlc_conv_desc.norm_out: the resident-weights form, tiles inside one image, the coefficient table of one image in 4 KiB of LDS
+int nlc_conv_pw_norm_ok(const KParams& pin, int dtype) {
+    KParams p = pin;
+    if (!p.norm_out) p.norm_out = reinterpret_cast<char*>(16);                  // (query before the buffer exists)
+    if (!p.gn_coef) p.gn_coef = reinterpret_cast<const float*>(16);
+    if (!nlc_conv_pw_ok(p, dtype) || !pwr_ok(p, pw_grid(p))) return 0;
+    if (((p.Hout * p.Wout) % PR_BM) != 0 || (p.C0 + p.C1) * 8 > PR_COEF_BYTES) return 0;
+    return 1;
+}
+
 int nlc_conv_pw_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     if (!nlc_conv_pw_ok(p, dtype)) return NLC_EUNSUPPORTED;
+    if (p.norm_out && !nlc_conv_pw_norm_ok(p, dtype)) return NLC_EUNSUPPORTED;
     static DeviceOnce once;
     const int ncu = once.ncu[nlc_device_once(once, [] {})];
     const int NTn = p.Cout / PW_BN;

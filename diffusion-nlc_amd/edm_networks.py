@@ -75,7 +75,10 @@ class _UNetBlock:
                          pack(sd, p + ".proj", dtype, device))
 
     def __call__(self, x, x1, emb_all):
-        h = self.n0(x, silu=True, x1=x1)
+        both = None
+        if self.skip is not None and not self.down and not self.up:
+            both = self.n0.with_skip(x, self.skip, silu=True, x1=x1)                # norm0 and the skip projection from one read
+        h, res = both if both is not None else (self.n0(x, silu=True, x1=x1), None)
         if self.down:
             h = ops.avgpool2x2(h)
         emb = None if self.emb_off is None else emb_all[:, self.emb_off:]
@@ -83,7 +86,9 @@ class _UNetBlock:
         if not self.pure:
             h = self.n1(h, silu=True)
         # PureUNetBlock.forward feeds conv0's output straight into conv1 (src/edm_networks.py:944-945)
-        if self.skip is not None:
+        if res is not None:
+            pass
+        elif self.skip is not None:
             xs, xs1 = x, x1
             if self.down:
                 xs = ops.avgpool2x2(x)

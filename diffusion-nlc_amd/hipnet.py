@@ -302,6 +302,18 @@ class Norm:
             return ops.groupnorm_pool2x2(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, silu=silu)
         return ops.avgpool2x2(self(x, silu=silu)), ops.avgpool2x2(x)
 
+    def with_skip(self, x, pw_skip, *, silu: bool, x1=None):
+        """(act(norm(cat(x, x1))), skip(cat(x, x1))) from ONE read of the input - the 1x1 skip projection of a ResBlock writes the
+        normalised activation for the block's first 3x3 as a side output (nlc_conv_desc.norm_out) - or None when this launch cannot
+        (the caller then runs the two passes)."""
+        if not ops.FUSE_GN_SKIP or not ops.conv2d(x, pw_skip, x1=x1, query_norm_out=True):
+            return None
+        coef = ops.groupnorm_coef(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, x1=x1)
+        if coef is None:
+            return None
+        res, hn = ops.conv2d(x, pw_skip, x1=x1, gn_coef=coef, gn_act=ACT_SILU if silu else ACT_NONE, norm_out=True, emit_stats=False)
+        return hn, res
+
     def then_conv(self, x, pw, *, silu: bool, x1=None, scale=None, shift=None, **conv_kw):
         """conv(act(norm(cat(x, x1)))) - with the normalisation applied inside the convolution's LDS prologue when the launch
         supports it and the statistics rode along with x (x1), else as the separate GroupNorm pass followed by the conv."""

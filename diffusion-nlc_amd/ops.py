@@ -261,7 +261,8 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
            emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, out_scale: float = 1.0,
            act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True,
            emit_stats: bool = True, allow_split: bool = False, gn_coef: Optional[torch.Tensor] = None,
-           gn_act: int = ACT_NONE, query_prologue: bool = False, res_upsample2x: bool = False):
+           gn_act: int = ACT_NONE, query_prologue: bool = False, res_upsample2x: bool = False,
+           norm_out: bool = False, query_norm_out: bool = False):
     """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1).
     ``emit_stats``: let the epilogue also write the GroupNorm statistics of the output when the launch supports it
     (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass.
@@ -271,7 +272,10 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
     on its way through LDS (coefficients from ``groupnorm_coef``); ``query_prologue=True`` only asks whether this launch
     could do that (returns bool, launches nothing).
     ``res_upsample2x``: ``res`` is [B, Hout/2, Wout/2, Cout] and is added nearest-2x upsampled (the skip branch of an
-    up-sampling ResBlock, src/unet_adm.py:186-190) - read in place, no upsampled copy in HBM."""
+    up-sampling ResBlock, src/unet_adm.py:186-190) - read in place, no upsampled copy in HBM.
+    ``norm_out`` (with ``gn_coef`` / ``gn_act``): a pointwise launch also writes gn_act(GroupNorm(cat(x0, x1))) - the convolution itself
+    runs on the input as given - and ``(out, normalised)`` is returned: a ResBlock's skip projection and the GroupNorm + SiLU in front
+    of its first 3x3 from one read of the input.  ``query_norm_out=True`` only asks whether this launch could (bool)."""
     lib = _ext.load()
     dt = pw.dtype
     linear = x0.dim() == 2
@@ -324,6 +328,14 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  res_upsample2x=1 if res_upsample2x else 0, math=pw.math, debug=CONV_DEBUG, w_scale=_ptr(pw.w_scale))
     if query_prologue:
         return bool(lib.nlc_conv2d_prologue_supported(C.byref(d), dtype_enum(dt)))
+    if query_norm_out:
+        return bool(lib.nlc_conv2d_norm_out_supported(C.byref(d), dtype_enum(dt)))
+    hn = None
+    if norm_out:
+        if gn_coef is None:
+            raise ValueError("conv2d: norm_out needs gn_coef (groupnorm_coef)")
+        hn = torch.empty(B, Hin, Win, C0 + C1, device=x0.device, dtype=dt)
+        d.norm_out = hn.data_ptr()
     if gn_coef is not None:
         if gn_coef.dtype != torch.float32 or not gn_coef.is_cuda or gn_coef.numel() < B * pw.Cin * 2 + 128:
             raise ValueError("conv2d: gn_coef must be a CUDA f32 [B, Cin, 2] table with >= 512 bytes of slack (groupnorm_coef)")
@@ -352,6 +364,8 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         _launch_conv(lib, d, dt)
     if linear and not out_nchw_f32:
         out = out.view(B, pw.Cout)
+    if norm_out:
+        return out, hn
     return out
 
 
@@ -385,7 +399,7 @@ def reset_conv_workspaces() -> None:
 def config_key() -> tuple:
     """Every module-level switch that changes which kernels / layouts a network evaluation launches.  HipModule keys its captured
     hipGraphs by it (a graph bakes the configuration it was captured under); setters of these switches need no other hook."""
-    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_POOL, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2, WS_GENERATION)
+    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_POOL, FUSE_GN_SKIP, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2, WS_GENERATION)
 
 
 def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,
@@ -540,6 +554,7 @@ def groupnorm_pool2x2_supported(x: torch.Tensor) -> bool:
 # 8.4 ms - every (16x16 patch x 128 cout) tile normalises its own halo, i.e. each input element NT x 1.27 = 2.5 ... 5 times, on
 # the same SIMD issue ports the MFMAs need: 5.89 vs 6.16 images/s (profiles/r02_summary.md).  Kept, tested, one switch away.
 FUSE_GN_CONV = False
+FUSE_GN_SKIP = True          # Norm.with_skip: a ResBlock's skip projection also writes act(GroupNorm(x)) of its input (nlc_conv_desc.norm_out)
 
 
 def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1: Optional[torch.Tensor] = None,
@@ -548,7 +563,7 @@ def groupnorm_coef(x0: torch.Tensor, gamma, beta, *, groups: int, eps: float, x1
     with the producing convolutions - for conv2d(gn_coef=...).  None when they are not available (f32 models, inputs without
     attached statistics, group sizes that 8-channel chunks cannot express): the caller then runs groupnorm()."""
     lib = _ext.load()
-    if not FUSED_GN_STATS or x0.dtype != torch.bfloat16:     # (the LDS prologue exists for bf16 only)
+    if not FUSED_GN_STATS or not is16(x0.dtype):             # (totals ride along with 16-bit tensors only)
         return None
     B, C0 = x0.shape[0], x0.shape[-1]
     C1 = 0 if x1 is None else x1.shape[-1]

@@ -71,14 +71,22 @@ class _ResBlock:
                 raise NotImplementedError("down-sampling ResBlock on a concatenated input (the reference has none)")
             h, x = self.n1.pooled(x, silu=True)                # one read of x for both branches, no full-resolution h
             h = ops.conv2d(h, self.c1, emb=c1_emb)
-        else:                                                  # GroupNorm+SiLU applied inside the conv's LDS prologue when it can be
-            h = self.n1.then_conv(x, self.c1, silu=True, x1=x1, upsample2x=self.up, emb=c1_emb)
+        res = None
+        if not self.down:
+            both = self.n1.with_skip(x, self.skip, silu=True, x1=x1) if (self.skip is not None and not self.up) else None
+            if both is not None:                               # in_layers(x) and skip_connection(x) (:236, :256) from one read of x
+                hn, res = both
+                h = ops.conv2d(hn, self.c1, emb=c1_emb)
+            else:                                              # GroupNorm+SiLU applied inside the conv's LDS prologue when it can be
+                h = self.n1.then_conv(x, self.c1, silu=True, x1=x1, upsample2x=self.up, emb=c1_emb)
         res_ups = False
         if self.up and self.skip is None:
             res_ups = True                                     # x_upd(x): read nearest-2x upsampled by the conv's epilogue, never materialised
         elif self.up:
             x = ops.upsample2x(x)
-        if self.skip is not None:
+        if res is not None:
+            pass
+        elif self.skip is not None:
             res = ops.conv2d(x, self.skip, x1=x1)
         else:
             res = x

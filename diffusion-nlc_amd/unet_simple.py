@@ -50,11 +50,13 @@ class _ResnetBlock:
         self.emb_off = bank.add(sd[p + ".temb_proj.weight"], sd[p + ".temb_proj.bias"])[0] if bank is not None else None
 
     def __call__(self, x, x1, emb_all):
-        h = self.n1(x, silu=True, x1=x1)
+        both = self.n1.with_skip(x, self.nin, silu=True, x1=x1) if self.nin is not None else None      # norm1 and nin_shortcut: one read
+        h, res = both if both is not None else (self.n1(x, silu=True, x1=x1), None)
         emb = None if self.emb_off is None else emb_all[:, self.emb_off:]
         h = ops.conv2d(h, self.c1, emb=emb)
         h = self.n2(h, silu=True)
-        res = ops.conv2d(x, self.nin, x1=x1) if self.nin is not None else x
+        if res is None:
+            res = ops.conv2d(x, self.nin, x1=x1) if self.nin is not None else x
         return ops.conv2d(h, self.c2, res=res)
 
 

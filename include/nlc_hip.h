@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 5
+#define NLC_ABI_VERSION 6
 
 enum { NLC_F32 = 0, NLC_BF16 = 1, NLC_F16 = 2 };
 /* matrix arithmetic of nlc_conv2d on NLC_F32 tensors (nlc_conv_desc.math; weights must be packed for the same mode):
@@ -178,6 +178,12 @@ typedef struct nlc_conv_desc {
     const float* w_scale; /* NLC_MATH_F16X3: f32 [Cout_pad] from nlc_pack_conv_weights_ex (w_scale_out), REQUIRED in that mode: the     */
                          /* conv sum of output channel n is multiplied by w_scale[n] (a power of two: exact) before bias / embedding /  */
                          /* residual are added.  Must be NULL for NLC_MATH_NATIVE.                                                       */
+    void* norm_out;      /* NULL, or (ABI v6) [B][Hin][Win][C0+C1] of the tensor dtype: a pointwise (1x1, stride 1) launch then ALSO writes */
+                         /* gn_act(a[b][c] * x + b[b][c]) of its input there (gn_coef REQUIRED: the table of nlc_groupnorm_coef), while    */
+                         /* the convolution itself runs on x as given - the skip projection of a ResBlock and the GroupNorm + SiLU in      */
+                         /* front of its first 3x3 from ONE read of cat(x0, x1) (/root/reference/src/unet_adm.py:236-256: in_layers(x)      */
+                         /* and skip_connection(x)).  Only launches for which nlc_conv2d_norm_out_supported(desc, dtype) returns 1          */
+                         /* (16-bit, C0 and C1 multiples of 128, C0+C1 <= 512, maps of whole multiples of 64 pixels, >= 1536 output tiles). */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
@@ -190,6 +196,8 @@ int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype);
 /* 1 if nlc_conv2d would apply desc.gn_coef / gn_act in its LDS prologue for this descriptor (geometry, dtype and policy decide;
  * the gn_* fields themselves are not looked at), else 0: the caller then runs nlc_groupnorm(_prestats) as a separate pass */
 int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype);
+/* 1 if nlc_conv2d would honour desc->norm_out for this descriptor (norm_out / gn_coef themselves are not looked at), else 0 */
+int nlc_conv2d_norm_out_supported(const nlc_conv_desc* d, int dtype);
 
 /* First-layer convolution for tiny Cin (<=4): reads the sampler state in the reference's
  * own layout (NCHW f32), applies the per-sample input scale c_in[b] (convert_coordinate,

@@ -1214,3 +1214,52 @@ def test_conv2d_pointwise_persistent_kernel(case, t16):
     s_ref, q_ref = ch.sum(dim=(1, 3)), (ch ** 2).sum(dim=(1, 3))
     assert (tot[..., 0] - s_ref).abs().max() <= 3e-3 * max(s_ref.abs().max().item(), 1.0)
     assert ((tot[..., 1] - q_ref) / q_ref).abs().max() <= 2e-3
+
+
+NORM_OUT_CASES = [
+    dict(B=2, C0=256, C1=256, H=256, W=256, Cout=256),       # ADM-256's 256x256 output blocks: K = 512 over both segments, two channel tiles
+    dict(B=4, C0=128, C1=128, H=256, W=256, Cout=128),       # one channel tile: the workgroup normalises every stage itself
+    dict(B=8, C0=384, C1=0, H=128, W=128, Cout=512),         # K = 384 from one segment, four channel tiles (stage kb by workgroup kb % 4)
+]
+
+
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+@pytest.mark.parametrize("case", NORM_OUT_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_pointwise_with_normalised_side_output(case, t16):
+    """nlc_conv_desc.norm_out (conv_pwr_kernel<.., NORM>): the skip projection of a ResBlock and act(GroupNorm(x)) of the same input from
+    one read.  The convolution output must equal the plain launch bit for bit (same kernel arithmetic, x is used unnormalised); the
+    normalised output must equal the separate GroupNorm pass to one rounding of a*x+b, and the f32 GroupNorm of the rounded input."""
+    from diffusion_nlc_amd import ops
+    B, C0, C1, H, W, Cout = (case[k] for k in ("B", "C0", "C1", "H", "W", "Cout"))
+    g = torch.Generator().manual_seed(_seed(case))
+    C = C0 + C1
+    src = _nhwc(torch.randn(B, 64, H, W, generator=g), t16)
+    def producer(cout, bias):      # a 3x3 convolution whose epilogue leaves the GroupNorm statistics of its output
+        w = torch.randn(cout, 64, 3, 3, generator=g) / 24
+        return ops.conv2d(src, ops.pack_conv(w, torch.full((cout,), bias), t16, _dev()))
+    h0 = producer(C0, 0.3)
+    h1 = producer(C1, -0.2) if C1 else None
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(_dev())
+    beta = (0.1 * torch.randn(C, generator=g)).to(_dev())
+    wsk = torch.randn(Cout, C, 1, 1, generator=g) / math.sqrt(C)
+    pw = ops.pack_conv(wsk, torch.randn(Cout, generator=g) * 0.2, t16, _dev())
+    plain_skip = ops.conv2d(h0, pw, x1=h1)
+    plain_hn = ops.groupnorm(h0, gamma, beta, groups=32, eps=1e-5, silu=True, x1=h1)
+    assert ops.conv2d(h0, pw, x1=h1, query_norm_out=True)
+    coef = ops.groupnorm_coef(h0, gamma, beta, groups=32, eps=1e-5, x1=h1)
+    assert coef is not None
+    outs = [ops.conv2d(h0, pw, x1=h1, gn_coef=coef, gn_act=1, norm_out=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    (skip, hn), (skip2, hn2) = outs
+    assert torch.equal(skip, skip2) and torch.equal(hn, hn2)                      # deterministic (counted waits behind two store streams)
+    assert torch.equal(skip, plain_skip)
+    assert ops.ride_stats(skip) is not None and torch.equal(ops.ride_stats(skip), ops.ride_stats(plain_skip))
+    a, b_ = hn.float().cpu(), plain_hn.float().cpu()
+    ulp = 2.0 ** (-7 if t16 == torch.bfloat16 else -10)
+    assert ((a - b_).abs() <= 2 * ulp * torch.maximum(a.abs(), b_.abs()) + 1e-3).all()
+    xcat = torch.cat([h0.float().cpu()] + ([h1.float().cpu()] if C1 else []), dim=3).permute(0, 3, 1, 2)
+    ref = F.silu(F.group_norm(xcat, 32, gamma.cpu(), beta.cpu(), eps=1e-5))
+    _close(hn.permute(0, 3, 1, 2), ref, _tol(t16) * 1.5, "normalised side output")
+    # a launch the resident pointwise kernel does not take must say so
+    small = _nhwc(torch.randn(1, 64, 32, 32, generator=g), t16)
+    assert not ops.conv2d(small, ops.pack_conv(torch.randn(128, 64, 1, 1, generator=g), None, t16, _dev()), query_norm_out=True)
