@@ -70,6 +70,37 @@ def test_adm256_bf16_first_step_tracks_f32(adm256):
     assert torch.isfinite(out_bf).all() and err <= 6e-2 * scale and rel_rms <= 2e-2
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_adm256_skip_projection_with_normalised_side_output_equals_the_two_passes(adm256, prec):
+    """ops.FUSE_GN_SKIP at the benchmark batch (the launches only qualify from ~1 500 output tiles on): one evaluation of the
+    full-size network with the ResBlocks' skip projection writing act(GroupNorm(x)) as a side output (nlc_conv_desc.norm_out) against
+    the separate GroupNorm pass + plain 1x1 - the skip outputs are bit-identical, the normalised activations differ by one rounding
+    of a*x+b in a few elements, so eps agrees far inside the 16-bit noise of the network (~1e-2 of scale)."""
+    from diffusion_nlc_amd import ops
+    exp = adm256
+    _set_precision(exp, prec)
+    try:
+        g = torch.Generator().manual_seed(11)
+        x = (torch.randn(16, 3, 256, 256, generator=g) * 20).to("cuda:0")
+        t = torch.linspace(900.0, 100.0, 16, device="cuda:0")
+        c_in = torch.full((16,), 0.04, device="cuda:0")
+        outs = {}
+        for flag in (True, False, True):
+            old = ops.FUSE_GN_SKIP
+            ops.FUSE_GN_SKIP = flag
+            try:
+                outs.setdefault(flag, []).append(exp.model.run(x, t, mode="forward", in_scale=c_in).clone())
+            finally:
+                ops.FUSE_GN_SKIP = old
+        fused, fused2, plain = outs[True][0], outs[True][1], outs[False][0]
+        assert torch.equal(fused, fused2)
+        scale = plain.float().pow(2).mean().sqrt().item()
+        rms = (fused.float() - plain.float()).pow(2).mean().sqrt().item()
+        assert torch.isfinite(fused).all() and rms <= 2e-3 * scale, (rms, scale)
+    finally:
+        _set_precision(exp, "bf16")
+
+
 @pytest.fixture(scope="module")
 def adm256_oracle():
     """The CPU oracle on the headline model itself (ADM-256, 614 M parameters, 256x256): the first ADM_STEPS timesteps of the
