@@ -582,7 +582,9 @@ def roofline_leg(wl, x, dtype, args, ms_per_step):
            # conv time of the instrumented step over the TIMED region's ms_per_step (reproducible from this line:
            # launches x avg_launch_us / ms_per_step); the instrumented step itself ran `instrumented_step_ms`
            "share_of_step": tot_ms / ms_per_step, "instrumented_step_ms": 1e3 * wall, "dominant_frac": None,
-           "measured": "HIP events around every conv launch of one extra (untimed) step"}
+           "measured": "HIP events around every conv launch of one extra (untimed) step",
+           "note": "the 1x1 skip projections of the ResBlocks also write act(GroupNorm(x)) of their input (nlc_conv_desc.norm_out): "
+                   "their whole launch time counts here, the GroupNorm pass it replaces never did"}
     dom = []
     if wl.name == "adm256" and wl.res == 256:
         # the dominant launch's OWN fraction of peak (conv3x3 256->256 @256x256: the largest single share of the step)
