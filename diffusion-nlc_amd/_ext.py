@@ -136,6 +136,8 @@ SIGNATURES = {
     "nlc_sigma_correct": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "nlc_proj_sigma": (C.c_int, [_vp, _f, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "nlc_dynamic_threshold": (C.c_int, [_vp, _f, _f, _vp, _i, _i64, _vp]),
+    "nlc_dynamic_threshold_ws_bytes": (C.c_int64, [_i]),
+    "nlc_dynamic_threshold_ws": (C.c_int, [_vp, _f, _f, _vp, _i, _i64, _vp, _i64, _vp]),
     "nlc_sched_x0": (C.c_int, [C.POINTER(SchedDesc), _vp]),
     "nlc_sched_step": (C.c_int, [C.POINTER(SchedDesc), _vp, _vp]),
     "nlc_scale_rows": (C.c_int, [_vp, _vp, _f, _vp, _i, _i64, _vp]),

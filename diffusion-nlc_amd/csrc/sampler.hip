@@ -239,6 +239,120 @@ __global__ __launch_bounds__(RT) void quantile_kernel(const float* __restrict__ 
     }
 }
 
+// ---- the same quantile with G workgroups per sample (nlc_dynamic_threshold_ws): the single-workgroup form above reads a sample five
+//      times through ONE CU (16 CUs busy at B = 16: 175 us for 12.6 MB).  Here every digit pass is two launches - slices of the sample
+//      histogrammed by G workgroups into a global per-sample histogram (integer atomics: order-free, exact), then one workgroup per
+//      sample scans it, picks the bin and clears it - and the kernel boundary is the only synchronisation: no workgroup ever waits for
+//      another.  Workspace per sample (u32): [4][256] histograms + {prefix, k, count <= value, 0x7fffffff - next larger value, ...};
+//      all zero on entry, all zero again on exit.  Same arithmetic as above, so the result is bit-identical to it and to torch.quantile.
+constexpr int QW_WORDS = 4 * 256 + 8;
+constexpr int QT = 256;
+
+__device__ __forceinline__ unsigned q_rank0(float q, int64_t D) { return (unsigned)floorf(q * (float)(D - 1)); }
+
+__global__ __launch_bounds__(QT) void qhist_kernel(const float* __restrict__ x, int64_t D, int pass, unsigned* __restrict__ ws) {
+    constexpr int NW = QT / 64;
+    __shared__ unsigned histw[NW][256];
+    const int g = blockIdx.x, G = gridDim.x, b = blockIdx.y, wv = threadIdx.x >> 6;
+    unsigned* w = ws + (int64_t)b * QW_WORDS;
+    const unsigned prefix = pass ? w[1024] : 0u;
+    const unsigned mask = pass ? (0xffffffffu << (32 - 8 * pass)) : 0u;
+    const int shift = 24 - 8 * pass;
+    for (int i = threadIdx.x; i < NW * 256; i += QT) (&histw[0][0])[i] = 0;
+    __syncthreads();
+    const float* row = x + (int64_t)b * D;
+    const int64_t i1 = D * (g + 1) / G;
+    int64_t i = D * g / G + threadIdx.x;
+    for (; i + 7 * QT < i1; i += 8 * QT) {
+        unsigned u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = abs_bits(row[i + e * QT]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if ((u[e] & mask) == prefix) atomicAdd(&histw[wv][(u[e] >> shift) & 255u], 1u);
+    }
+    for (; i < i1; i += QT) {
+        const unsigned u = abs_bits(row[i]);
+        if ((u & mask) == prefix) atomicAdd(&histw[wv][(u >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    unsigned a = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) a += histw[k][threadIdx.x];
+    if (a) atomicAdd(&w[pass * 256 + threadIdx.x], a);
+}
+
+__global__ __launch_bounds__(QT) void qscan_kernel(float q, int64_t D, int pass, unsigned* __restrict__ ws) {
+    __shared__ unsigned sc[QT];
+    unsigned* w = ws + (int64_t)blockIdx.x * QW_WORDS;
+    const int tid = threadIdx.x, shift = 24 - 8 * pass;
+    const unsigned prefix = pass ? w[1024] : 0u;
+    const unsigned k = pass ? w[1025] : q_rank0(q, D);
+    const unsigned c = w[pass * 256 + tid];
+    w[pass * 256 + tid] = 0;                                   // the histogram is zero again for the next call
+    sc[tid] = c;
+    for (int off = 1; off < QT; off <<= 1) {                   // inclusive prefix sum over the 256 bins
+        __syncthreads();
+        const unsigned v = tid >= off ? sc[tid - off] : 0u;
+        __syncthreads();
+        sc[tid] += v;
+    }
+    const unsigned incl = sc[tid], excl = incl - c;
+    if (excl <= k && k < incl) {                               // exactly one bin holds order statistic k (everyone has read prefix / k)
+        w[1024] = prefix | ((unsigned)tid << shift);
+        w[1025] = k - excl;
+    }
+}
+
+__global__ __launch_bounds__(QT) void qcount_kernel(const float* __restrict__ x, int64_t D, unsigned* __restrict__ ws) {
+    __shared__ unsigned s_cnt, s_nxt;
+    const int g = blockIdx.x, G = gridDim.x, b = blockIdx.y;
+    unsigned* w = ws + (int64_t)b * QW_WORDS;
+    const unsigned prefix = w[1024];                           // bit pattern of sorted[lo]
+    if (threadIdx.x == 0) { s_cnt = 0; s_nxt = 0x7fffffffu; }
+    __syncthreads();
+    const float* row = x + (int64_t)b * D;
+    const int64_t i1 = D * (g + 1) / G;
+    unsigned cnt = 0, nxt = 0x7fffffffu;
+    int64_t i = D * g / G + threadIdx.x;
+    for (; i + 7 * QT < i1; i += 8 * QT) {
+        unsigned u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = abs_bits(row[i + e * QT]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { if (u[e] <= prefix) ++cnt; else nxt = min(nxt, u[e]); }
+    }
+    for (; i < i1; i += QT) {
+        const unsigned u = abs_bits(row[i]);
+        if (u <= prefix) ++cnt; else nxt = min(nxt, u);
+    }
+    atomicAdd(&s_cnt, cnt);
+    atomicMin(&s_nxt, nxt);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_cnt) atomicAdd(&w[1026], s_cnt);
+        atomicMax(&w[1027], 0x7fffffffu - s_nxt);              // zero-initialised workspace: the maximum of (0x7fffffff - value)
+    }
+}
+
+__global__ void qfinish_kernel(float q, float max_value, int64_t D, float* __restrict__ s_out, unsigned* __restrict__ ws, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    unsigned* w = ws + (int64_t)b * QW_WORDS;
+    const unsigned prefix = w[1024], cnt_le = w[1026], nxt = 0x7fffffffu - w[1027];
+    w[1024] = 0; w[1025] = 0; w[1026] = 0; w[1027] = 0;
+    const float rank = q * (float)(D - 1);
+    const float rank_lo = floorf(rank);
+    const float wq = rank - rank_lo;
+    const float v_lo = __uint_as_float(prefix);
+    const unsigned lo_idx = (unsigned)rank_lo;
+    float v_hi = v_lo;
+    if (ceilf(rank) > rank_lo && cnt_le <= lo_idx + 1) v_hi = __uint_as_float(nxt);
+    const float diff = v_hi - v_lo;                            // at::lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+    float s = (wq < 0.5f) ? (v_lo + wq * diff) : (v_hi - diff * (1.0f - wq));
+    s_out[b] = fminf(fmaxf(s, 1.0f), max_value);
+}
+
 // ---- fused scheduler update ---------------------------------------------------------------
 struct SchedScalars {
     float st, sp, eps_mul, eps_div, min_lv, max_lv, abp;
@@ -463,6 +577,32 @@ extern "C" int nlc_dynamic_threshold(const float* x0_hat, float q, float max_val
     NLC_REQUIRE(D < (1ll << 24), "nlc_dynamic_threshold: D too large for exact f32 rank arithmetic");
     hipLaunchKernelGGL(quantile_kernel, dim3(B), dim3(RT), 0, (hipStream_t)stream, x0_hat, q, max_value, s_out, D);
     NLC_CHECK_LAUNCH("nlc_dynamic_threshold");
+    return NLC_OK;
+}
+
+extern "C" int64_t nlc_dynamic_threshold_ws_bytes(int B) { return B > 0 ? (int64_t)B * QW_WORDS * 4 : 0; }
+
+extern "C" int nlc_dynamic_threshold_ws(const float* x0_hat, float q, float max_value, float* s_out, int B, int64_t D,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+    NLC_REQUIRE(x0_hat && s_out && B > 0 && D > 1, "nlc_dynamic_threshold_ws: bad arguments");
+    NLC_REQUIRE(q >= 0.f && q <= 1.f, "nlc_dynamic_threshold_ws: q out of range");
+    NLC_REQUIRE(D < (1ll << 24), "nlc_dynamic_threshold_ws: D too large for exact f32 rank arithmetic");
+    NLC_REQUIRE(B <= 65535, "nlc_dynamic_threshold_ws: B too large");
+    NLC_REQUIRE(workspace && workspace_bytes >= nlc_dynamic_threshold_ws_bytes(B) && (reinterpret_cast<uintptr_t>(workspace) & 3) == 0,
+                "nlc_dynamic_threshold_ws: workspace of nlc_dynamic_threshold_ws_bytes(B) bytes (zeroed once by the caller) required");
+    unsigned* ws = reinterpret_cast<unsigned*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    int G = 512 / B;                                           // ~two workgroups per CU over the whole batch
+    const int gmax = (int)((D + 8 * QT - 1) / (8 * QT));       // ... each with at least one full trip of its load loop
+    if (G > gmax) G = gmax;
+    if (G < 1) G = 1;
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(qhist_kernel, dim3(G, B), dim3(QT), 0, st, x0_hat, D, pass, ws);
+        hipLaunchKernelGGL(qscan_kernel, dim3(B), dim3(QT), 0, st, q, D, pass, ws);
+    }
+    hipLaunchKernelGGL(qcount_kernel, dim3(G, B), dim3(QT), 0, st, x0_hat, D, ws);
+    hipLaunchKernelGGL(qfinish_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, q, max_value, D, s_out, ws, B);
+    NLC_CHECK_LAUNCH("nlc_dynamic_threshold_ws");
     return NLC_OK;
 }
 

@@ -723,14 +723,27 @@ def proj_sigma(sumsq, sqrt_dim, norm_max, norm_max_sq, costheta, term0, r1, r2, 
                              t.data_ptr(), B, _stream()), "nlc_proj_sigma")
 
 
-def dynamic_threshold(x0_hat: torch.Tensor, q: float, max_value: float) -> torch.Tensor:
+_QUANTILE_WS: dict = {}      # (device, B) -> zeroed int32 workspace of nlc_dynamic_threshold_ws (every call leaves it zeroed)
+
+
+def dynamic_threshold(x0_hat: torch.Tensor, q: float, max_value: float, single_workgroup: bool = False) -> torch.Tensor:
+    """Per-sample quantile of |x0_hat| (torch.quantile, exact), clamped to [1, max_value] (src/experiments.py: dynamic thresholding).
+    ``single_workgroup``: the one-launch form with one workgroup per sample (tests compare the two)."""
     lib = _ext.load()
     _need(x0_hat, torch.float32, "dynamic_threshold x")
     B = x0_hat.shape[0]
     D = x0_hat.numel() // B
     out = torch.empty(B, device=x0_hat.device, dtype=torch.float32)
-    check(lib.nlc_dynamic_threshold(x0_hat.data_ptr(), q, max_value, out.data_ptr(), B, D, _stream()),
-          "nlc_dynamic_threshold")
+    if single_workgroup:
+        check(lib.nlc_dynamic_threshold(x0_hat.data_ptr(), q, max_value, out.data_ptr(), B, D, _stream()),
+              "nlc_dynamic_threshold")
+        return out
+    key = (x0_hat.device, B)
+    ws = _QUANTILE_WS.get(key)
+    if ws is None:
+        ws = _QUANTILE_WS[key] = torch.zeros(lib.nlc_dynamic_threshold_ws_bytes(B) // 4, device=x0_hat.device, dtype=torch.int32)
+    check(lib.nlc_dynamic_threshold_ws(x0_hat.data_ptr(), q, max_value, out.data_ptr(), B, D, ws.data_ptr(), ws.numel() * 4, _stream()),
+          "nlc_dynamic_threshold_ws")
     return out
 
 

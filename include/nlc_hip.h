@@ -364,6 +364,12 @@ int nlc_proj_sigma(const float* sumsq, float sqrt_dim, float norm_max, float nor
  * interpolation and f32 rank arithmetic (src/experiments.py:190-199), exact radix select. */
 int nlc_dynamic_threshold(const float* x0_hat, float q, float max_value, float* s_out,
                           int B, int64_t D, void* stream);
+/* The same result (bit-identical) with G workgroups per sample and one launch pair per digit pass - the form the sampling loop uses:
+ * the single-workgroup kernel above keeps B CUs busy.  `workspace`: nlc_dynamic_threshold_ws_bytes(B) bytes of device memory that
+ * the caller zeroes ONCE; every call finds it zero and leaves it zero (calls on one workspace must be stream-ordered). */
+int64_t nlc_dynamic_threshold_ws_bytes(int B);
+int nlc_dynamic_threshold_ws(const float* x0_hat, float q, float max_value, float* s_out, int B, int64_t D,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* One fused scheduler update on the NCHW f32 state (src/experiments.py:360-370,
  * src/schedulers.py:367-390,407-449 and the variants listed in the NLC_SCHED_* enum).

@@ -523,11 +523,20 @@ def test_row_sumsq_and_quantile():
         y = torch.randn(*shape, generator=g) * 2.5
         y[0].mul_(0.2)                                   # below the clamp floor of 1
         ref = torch.quantile(y.reshape(shape[0], -1).abs(), q, dim=1).clamp(min=1, max=100)
-        got = ops.dynamic_threshold(y.to(_dev()), q, 100.0).cpu()
-        assert torch.equal(got, ref), (shape, got, ref)
+        for single in (False, True, False):              # G workgroups per sample (twice: the workspace must come back zeroed), and one
+            got = ops.dynamic_threshold(y.to(_dev()), q, 100.0, single_workgroup=single).cpu()
+            assert torch.equal(got, ref), (shape, single, got, ref)
     # ties everywhere
     z = torch.ones(2, 3, 8, 8) * 3.0
-    assert torch.equal(ops.dynamic_threshold(z.to(_dev()), 0.99, 100.0).cpu(), torch.tensor([3.0, 3.0]))
+    for single in (False, True):
+        assert torch.equal(ops.dynamic_threshold(z.to(_dev()), 0.99, 100.0, single_workgroup=single).cpu(), torch.tensor([3.0, 3.0]))
+    # the benchmark shape, heavy ties (a clipped image), q at both ends
+    y = (torch.randn(16, 3, 256, 256, generator=g) * 0.7).clamp(-1, 1)
+    for q in (0.995, 0.0, 1.0, 0.37):
+        ref = torch.quantile(y.reshape(16, -1).abs(), q, dim=1).clamp(min=1, max=100)
+        ref_raw = torch.quantile(y.reshape(16, -1).abs() + 1.0, q, dim=1).clamp(min=1, max=100)
+        assert torch.equal(ops.dynamic_threshold(y.to(_dev()), q, 100.0).cpu(), ref)
+        assert torch.equal(ops.dynamic_threshold((y.abs() + 1.0).to(_dev()), q, 100.0).cpu(), ref_raw)      # above the clamp floor
 
 
 @pytest.mark.parametrize("t16", T16, ids=T16_IDS)

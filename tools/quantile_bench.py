@@ -12,13 +12,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from diffusion_nlc_amd import ops  # noqa: E402
 
 x = torch.randn(16, 3 * 256 * 256, device="cuda:0")
-for _ in range(3):
-    ops.dynamic_threshold(x, 0.995, 1e9)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(50):
-    ops.dynamic_threshold(x, 0.995, 1e9)
-e1.record()
-torch.cuda.synchronize()
-print("dynamic_threshold [16, 196608]: %.1f us" % (e0.elapsed_time(e1) / 50 * 1e3))
+for single in (True, False):
+    for _ in range(3):
+        ops.dynamic_threshold(x, 0.995, 1e9, single_workgroup=single)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        ops.dynamic_threshold(x, 0.995, 1e9, single_workgroup=single)
+    e1.record()
+    torch.cuda.synchronize()
+    print("dynamic_threshold [16, 196608] %s: %.1f us" % ("one workgroup per sample, one launch " if single else "G workgroups per sample, 10 launches", e0.elapsed_time(e1) / 50 * 1e3))
