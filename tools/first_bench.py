@@ -12,18 +12,19 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from diffusion_nlc_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-x = torch.randn(16, 3, 256, 256, device=dev)
-w = torch.randn(256, 9, 3, device=dev) * 0.2          # [Cout][KH*KW][Cin]
-b = torch.zeros(256, device=dev)
-sc = torch.ones(16, device=dev)
-for _ in range(3):
-    ops.conv_first(x, w, b, torch.bfloat16, sc)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20):
-    ops.conv_first(x, w, b, torch.bfloat16, sc)
-e1.record()
-torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 20 * 1e3
-print(f"conv_first 3->256 @256^2 B=16: {us:.1f} us  ({16 * 65536 * 256 * 2 / us / 1e6:.2f} TB/s written)")
+for B, H, Cout in ((16, 256, 256), (8, 256, 128), (200, 32, 128)):        # ADM-256, CelebA-HQ-256 (cfg 4), EDM-32 (cfg 3)
+    x = torch.randn(B, 3, H, H, device=dev)
+    w = torch.randn(Cout, 9, 3, device=dev) * 0.2          # [Cout][KH*KW][Cin]
+    b = torch.zeros(Cout, device=dev)
+    sc = torch.ones(B, device=dev)
+    for _ in range(3):
+        ops.conv_first(x, w, b, torch.bfloat16, sc)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.conv_first(x, w, b, torch.bfloat16, sc)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print(f"conv_first 3->{Cout} @{H}^2 B={B}: {us:.1f} us  ({B * H * H * Cout * 2 / us / 1e6:.2f} TB/s written)")
