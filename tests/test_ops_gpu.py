@@ -1208,6 +1208,9 @@ def test_conv2d_pointwise_persistent_kernel(case, t16):
     torch.cuda.synchronize()
     (ya, sa), (yb, sb), (yc, sc_), (ye, se) = outs                         # tuning bit 16: the streaming form where the resident one would run
     assert torch.equal(ya, yb) and torch.equal(sa, sb)                      # deterministic, launch after launch
+    for _ in range(16):
+        yn = ops.conv2d(x0, pw, x1=x1, res=rs, out_scale=case["scale"])
+        assert torch.equal(yn, ya) and torch.equal(ops.ride_stats(yn), sa)
     _close(ya.permute(0, 3, 1, 2), ref, _tol(t16), "conv2d (pointwise kernel)")
     ulp = 2.0 ** (-7 if t16 == torch.bfloat16 else -10)
     a, c = ya.float().cpu(), yc.float().cpu()
@@ -1261,6 +1264,10 @@ def test_conv2d_pointwise_with_normalised_side_output(case, t16):
     torch.cuda.synchronize()
     (skip, hn), (skip2, hn2) = outs
     assert torch.equal(skip, skip2) and torch.equal(hn, hn2)                      # deterministic (counted waits behind two store streams)
+    for _ in range(24):                                                           # ... launch after launch, other launches in between
+        ops.groupnorm(h0, gamma, beta, groups=32, eps=1e-5, silu=True, x1=h1)
+        s_n, h_n = ops.conv2d(h0, pw, x1=h1, gn_coef=coef, gn_act=1, norm_out=True)
+        assert torch.equal(s_n, skip) and torch.equal(h_n, hn)
     assert torch.equal(skip, plain_skip)
     assert ops.ride_stats(skip) is not None and torch.equal(ops.ride_stats(skip), ops.ride_stats(plain_skip))
     a, b_ = hn.float().cpu(), plain_hn.float().cpu()
