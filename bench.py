@@ -110,8 +110,9 @@ class AdmWorkload:
         self.headline = self.res == 256 and self.timesteps == 50
         self.metric = ("images/sec whole-node, 256x256 50-step DDIM+NLC" if self.headline
                        else f"images/sec, {self.res}x{self.res} {self.timesteps}-step DDIM+NLC (debug configuration)")
-        self.workload = (f"ADM UNet {self.res}x{self.res} (src/unet_adm.py), {self.timesteps}-step DDIM+NLC, batch {self.batch} per GPU, "
-                         f"{args.dtype}, dynamic-threshold clip, learned variance, filler weights")
+        # (kept under 120 characters: the driver's record cuts longer strings)
+        self.workload = (f"ADM UNet {self.res}x{self.res} (src/unet_adm.py), {self.timesteps}-step DDIM+NLC, batch {self.batch}/GPU, {args.dtype}, "
+                         "dynamic clip, learned var, filler weights")
         self.gflop_per_image = self.timesteps * GF_PER_IMAGE_STEP if self.res == 256 else None
 
     @staticmethod
@@ -387,6 +388,71 @@ class CelebaWorkload:
 
 WORKLOADS = {"adm256": AdmWorkload, "edm32": EdmWorkload, "celebahq256": CelebaWorkload}
 
+# BASELINE.json configs[0] / BASELINE.md §3b item 3: the reference's own CPU-runnable case - unet_simple 32x32, 10-step DDIM+NLC,
+# batch 4 (image_sample.py --synthetic cifar_tiny; tests/golden/loop_simple_pred.npz is the reference's own run of it)
+CFG0 = dict(ch=64, out_ch=3, ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[16], dropout=0.0, in_channels=3,
+            resamp_with_conv=True, feat_layer=1, type="simple", sigma_block=2, sigma_dropout=0.0)
+
+
+def cfg0_baseline(device):
+    """configs[0] run IN FULL on the host cores (the oracle = CPU port of the reference loop), then the same seeded x_T on the HIP path
+    in f32: images/sec of the CPU run, and the per-pixel L-inf between the two final samples."""
+    from diffusion_nlc_amd import script_util
+    from diffusion_nlc_amd.experiments import ImageExperiment
+    from diffusion_nlc_amd.filler import fill_state_dict
+    from diffusion_nlc_amd.schedulers import get_sampler as hip_sampler
+    from oracle import simple
+    from oracle.loop import DiffusionOracle
+    from oracle.sched import get_sampler
+    torch.set_num_threads(_host_cores())
+    ns = argparse.Namespace
+    config = ns(model=ns(**CFG0), data=ns(image_size=32), diffusion=ns(num_diffusion_timesteps=1000))
+    eps, sig, _ = script_util.create_simple_sigma_eps_model(config)
+    sd_e = fill_state_dict(eps.state_dict(), seed=0)
+    sd_s = fill_state_dict(sig.state_dict(), seed=1, overrides=SIGMA_OVERRIDES)
+    cfg = simple.SimpleConfig(ch=64, out_ch=3, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,), in_channels=3,
+                              resolution=32, resamp_with_conv=True, feat_layer=1, sigma_block=2)
+    _, dim = simple.sigma_dims(cfg)
+    B, steps, shape = 4, 10, (4, 3, 32, 32)
+    kw = dict(sigma_style="DDIM", start_sigma=100, end_sigma=0, sampler_var="fixedsmall", eta=0.0)
+    s = get_sampler("ddim", 1000, steps, **kw)
+    o = DiffusionOracle(lambda x, t: simple.unet(sd_e, cfg, x, t, "forward"), lambda x, t: simple.unet(sd_e, cfg, x, t, "encode"),
+                        lambda f: simple.sigma_net(sd_s, dim, cfg.sigma_block, f), s, (3, 32, 32), learn_epsvar=False,
+                        norm_min=0.0, norm_max=54.63, clip_fn="clamp")
+    z = torch.randn(shape, generator=torch.Generator().manual_seed(1234))
+    xT = z / (1 / (s.sampling_sigmas[0] ** 2 + 1)).sqrt()
+    run_cpu = lambda: o.denoise_loop(shape, style="pred", norm_eps=True, refine_prior_sigma=True, xT=xT.clone(), sigma_pred_threshold=960)
+    run_cpu()                                                   # untimed: thread pool, allocator
+    n, t0 = 0, time.perf_counter()
+    while n == 0 or (time.perf_counter() - t0 < 6.0 and n < 50):
+        x_cpu = run_cpu()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    out = {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n} full runs of unet_simple 32x32 (ch 64, mult 1-2-2), 10-step DDIM+NLC, batch {B}, f32 on the host ({dt:.2f} s each); "
+                     "nothing extrapolated"}
+    eps.load_state_dict(sd_e)
+    sig.load_state_dict(sd_s)
+    eps.to(device)
+    sig.to(device)
+    hs = hip_sampler("ddim", 1000, steps, **kw)
+    hs.to(device)
+    exp = ImageExperiment(eps, hs, batch_size=B, data_shape=(3, 32, 32), seed=1234, device=device)
+    exp.set_model(eps, sig, learn_epsvar=False)
+    exp.set_norm_maxmin(0.0, 54.63)
+    exp.set_clip_fn("clamp")
+    run_hip = lambda: exp.denoise_loop(shape=shape, xT=xT.to(device), style="pred", norm_eps=True, refine_prior_sigma=True, return_log=False,
+                                       chunk_size=1, sigma_pred_threshold=960, return_on_device=True)[0]
+    x_hip = run_hip()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        x_hip = run_hip()
+    torch.cuda.synchronize()
+    out["hip_f32_images_per_sec"] = 5 * B / (time.perf_counter() - t0)
+    out["hip_f32_linf_vs_cpu"] = float((x_hip.cpu().double() - x_cpu.double()).abs().max())
+    return out
+
 
 def _host_cores():
     # the GPU box shares its host: a 1-GPU slot owns 16 cores (os.cpu_count() reports the whole machine)
@@ -544,6 +610,8 @@ def main():
             line["roofline"] = roofline_leg(wl, xs[0], dtype, args, line["ms_per_step"])
         if not args.dry_run and not args.no_cpu_baseline and not args.tiny and world == 1:
             line["cpu_baseline"] = wl.cpu_baseline()
+            if wl.name == "adm256":
+                line["cpu_baseline"]["configs0_unet_simple_32"] = cfg0_baseline(device)
             if hasattr(wl, "parity"):
                 par = wl.parity(args.dtype)
                 if par:

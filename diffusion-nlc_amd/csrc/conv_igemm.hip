@@ -414,7 +414,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
             const int P = nlc_conv_narrow_ok(p, dtype) ? 0 : (Phalo > 0 ? Phalo : Pfast);
             NLC_REQUIRE(P > 0, "nlc_conv2d: stats_out given but this launch does not emit statistics (ask nlc_conv2d_stats_partials first)");
             NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * (p.Cout / p.stats_gran) * 4 * (int64_t)sizeof(long long), "nlc_conv2d: stats_out too small");
-            NLC_REQUIRE((reinterpret_cast<uintptr_t>(d->stats_out) & 7) == 0, "nlc_conv2d: stats_out must be 8-byte aligned");
+            NLC_REQUIRE((reinterpret_cast<uintptr_t>(d->stats_out) & 15) == 0, "nlc_conv2d: stats_out must be 16-byte aligned (its consumers read 16-byte pairs)");
             p.stats = (long long*)d->stats_out;
         }
         if (p.norm_out) {                            // pointwise launch that also writes act(GroupNorm(x)) of its input

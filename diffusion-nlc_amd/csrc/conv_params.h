@@ -94,11 +94,23 @@ struct Stat16 {
     //      addition is associative, so the totals do not depend on the order in which workgroups arrive - bit-reproducible without a
     //      partials array, a fixed-order reduction pass or a finalize launch.  Resolution 2^-44 per contribution (5.7e-14), range
     //      +-2^63; the consumer (groupnorm.hip: gn_channel_coefs) reads value = hi + lo * 2^-44 in f64.
+    //      A contribution that is not finite or not below 2^45 in magnitude has no limbs (the conversion would be undefined): it sets
+    //      bit 62 of the chunk's sumsq.hi word with an atomic OR instead.  Legitimate sumsq.hi totals stay below 2^61 (< 2^16
+    //      contributions of < 2^45 each, never negative), so no add can carry into that bit and no add can clear it: the mark is
+    //      sticky and order-independent like the sums, and the consumer turns a marked chunk's group into NaN (mean, rstd) - what
+    //      F.group_norm gives for a group that holds an inf / NaN.
     static constexpr double LIMB = 17592186044416.0;           // 2^44
+    static constexpr float LIMB_DOMAIN = 35184372088832.f;     // 2^45
+    static constexpr unsigned long long POISON = 1ull << 62;
+    static __device__ __forceinline__ bool in_domain(float v) { return fabsf(v) < LIMB_DOMAIN; }      // false for NaN too
     static __device__ __forceinline__ void limbs(float v, long long& hi, long long& lo) {
         const double d = (double)v, fl = floor(d);
         hi = (long long)fl;
         lo = (long long)((d - fl) * LIMB);
+    }
+    // `word`: the accumulator a lane was about to add a limb of v to, index within its chunk = (word - base) & 3
+    static __device__ __forceinline__ void poison(long long* chunk_sumsq_hi) {
+        atomicOr(reinterpret_cast<unsigned long long*>(chunk_sumsq_hi), POISON);
     }
     // After a 16-lane all-reduce (every lane of the row holds the row's sums for its 16 channels from n): lane `fr` of the row adds
     // ONE limb - its index within the slice's 16 (per-4 granules) or 8 (per-8 chunks) accumulators - so that a wave issues a single
@@ -111,9 +123,10 @@ struct Stat16 {
 #pragma unroll
         for (int k = 1; k < 8; ++k) v = (vi == k) ? (gran == 4 ? v4[k] : v8[k]) : v;
         if (gran != 4 && fr >= 8) return;
+        long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4 + fr;
+        if (!in_domain(v)) { poison(dst - (fr & 3) + 2); return; }
         long long hi, lo;
         limbs(v, hi, lo);
-        long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4 + fr;
         atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)((fr & 1) ? lo : hi));
     }
     // The same for a lane that holds 8 channels from n (in s[0..1], q[0..1]: add_chunk(0, .) only): 8 (per-4 granules) or 4 (one per-8
@@ -126,9 +139,10 @@ struct Stat16 {
         float v = gran == 4 ? v4[0] : v8[0];
 #pragma unroll
         for (int k = 1; k < 4; ++k) v = (vi == k) ? (gran == 4 ? v4[k] : v8[k & 1]) : v;
+        long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4 + fr;
+        if (!in_domain(v)) { poison(dst - (fr & 3) + 2); return; }
         long long hi, lo;
         limbs(v, hi, lo);
-        long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4 + fr;
         atomicAdd(reinterpret_cast<unsigned long long*>(dst), (unsigned long long)((fr & 1) ? lo : hi));
     }
     // one lane alone adds everything it holds (launches whose 16-pixel rows may straddle two images: never taken by the networks)
@@ -138,8 +152,10 @@ struct Stat16 {
         long long* dst = tot + (gran == 4 ? ((int64_t)b * (Cout >> 2) + (n >> 2)) : ((int64_t)b * (Cout >> 3) + (n >> 3))) * 4;
         const int nv = gran == 4 ? 8 : 4;
         for (int k = 0; k < nv; ++k) {
+            const float v = gran == 4 ? v4[k] : v8[k];
+            if (!in_domain(v)) { poison(dst + (k >> 1) * 4 + 2); continue; }
             long long hi, lo;
-            limbs(gran == 4 ? v4[k] : v8[k], hi, lo);
+            limbs(v, hi, lo);
             atomicAdd(reinterpret_cast<unsigned long long*>(dst + 2 * k), (unsigned long long)hi);
             atomicAdd(reinterpret_cast<unsigned long long*>(dst + 2 * k + 1), (unsigned long long)lo);
         }

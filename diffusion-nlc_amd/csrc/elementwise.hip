@@ -380,7 +380,7 @@ extern "C" int nlc_conv_first(const float* x_nchw, const float* in_scale, const 
             NLC_REQUIRE(nb > 0 && (Cout % 16) == 0 && ((int64_t)H * W) % F1_PIX == 0,
                         "nlc_conv_first: stats_out given but this launch does not emit statistics (ask nlc_conv_first_stats_partials)");
             NLC_REQUIRE(stats_bytes >= (int64_t)B * (Cout / gran) * 4 * (int64_t)sizeof(long long), "nlc_conv_first: stats_out too small");
-            NLC_REQUIRE((reinterpret_cast<uintptr_t>(stats_out) & 7) == 0, "nlc_conv_first: stats_out must be 8-byte aligned");
+            NLC_REQUIRE((reinterpret_cast<uintptr_t>(stats_out) & 15) == 0, "nlc_conv_first: stats_out must be 16-byte aligned (its consumers read 16-byte pairs)");
         }
         if (nb > 0) {
             const int ntile = (int)(((int64_t)H * W + F1_PIX - 1) / F1_PIX);

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const GNParams p, float
 // array, no reduction pass and no finalize launch between a convolution and the normalisation that follows it.
 __device__ __forceinline__ void gn_group_from_totals(const GNParams& p, int b, int g, float& mean, float& rstd) {
     double S = 0.0, Q = 0.0;
+    long long marks = 0;             // bit 62 of a chunk's sumsq.hi word: a contribution was inf / NaN / out of the limbs' domain (Stat16::poison)
     const int ch = g * p.gs, ch1 = ch + p.gs;
     auto add = [&](const long long* tot, int nq, int first_chunk, int nchunk) {      // the group's chunks of one source are contiguous
         const longlong2* t = reinterpret_cast<const longlong2*>(tot + ((int64_t)b * nq + first_chunk) * 4);
@@ -308,6 +309,7 @@ __device__ __forceinline__ void gn_group_from_totals(const GNParams& p, int b, i
             const longlong2 ts = t[2 * k], tq = t[2 * k + 1];
             S += (double)ts.x + (double)ts.y * (1.0 / Stat16::LIMB);
             Q += (double)tq.x + (double)tq.y * (1.0 / Stat16::LIMB);
+            marks |= tq.x;
         }
     };
     const int e0 = min(ch1, p.C0), s1 = max(ch, p.C0);
@@ -318,6 +320,7 @@ __device__ __forceinline__ void gn_group_from_totals(const GNParams& p, int b, i
     if (var < 0.0) var = 0.0;
     mean = (float)mean_d;
     rstd = rsqrtf((float)(var + (double)p.eps));         // (the totals describe 16-bit tensors: a 1-ulp f32 reciprocal square root is ample)
+    if (marks & (long long)Stat16::POISON) mean = rstd = __builtin_nanf("");
 }
 
 // nlc_groupnorm_coef: the (a, b) table of GroupNorm (+FiLM) per (image, channel) from the totals, for a convolution that applies the

@@ -246,7 +246,9 @@ class ExperimentDiffusion:
             ops.sigma_correct(r, style != "pred", S.device_sigmas(self.device), st["sigma_t"], st["sigma_prev"], st["t"],
                               st["c_in"], t_slopes=slopes)
         # the reference evaluates the eps network on len(xt) // chunk_size samples at a time (src/experiments.py:436-450: memory
-        # only - no op of the networks couples samples, so the result is the same bit for bit; tests/test_loop_gpu.py)
+        # only - no op of the networks couples samples, so the result is the same up to the f32 summation order of the kernels
+        # that the per-launch batch selects (split-K, attention DMA form, pointwise tile thresholds): tests/test_loop_gpu.py gates
+        # 1e-4.  chunk_size > 1 also shrinks every launch of the eps network: the CLIs and bench.py pass 1)
         micro = max(B // max(int(chunk_size), 1), 1)
         if micro >= B:
             eps_out = self.model.run(xt, st["t"], mode="forward", in_scale=st["c_in"])

@@ -67,13 +67,32 @@ def _graphable(fn):
     memory pool and then replayed with ONE hipGraphLaunch.  Inputs are copied into the capture's static buffers unless
     the caller already passes those; the returned tensors are the capture's static outputs - valid until the next
     replay of the same graph (the sampling loops consume them before they evaluate the network again): a caller that keeps
-    an ``eps`` / ``feat`` tensor across another evaluation of the same entry point must ``clone()`` it."""
+    an ``eps`` / ``feat`` tensor across another evaluation of the same entry point must ``clone()`` it.  The ride-along
+    GroupNorm statistics of a returned tensor are copied out of the module's arena into storage of the graph's own pool
+    (``_own_output_stats``), so they live exactly as long as the tensor's data: another graph, an eager call or another entry
+    point of the same module re-zeroes the arena, not them."""
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
         if not self.use_graphs or torch.cuda.is_current_stream_capturing():
             return self._eval(fn, args, kwargs)
         return self._graph_call(fn, args, kwargs)
     return wrapper
+
+
+def _own_output_stats(out) -> None:
+    """Inside a capture: give every returned tensor a private copy of its ride-along statistics (slices of the module's ONE arena
+    otherwise - rewritten by the next evaluation of any entry point of the module, while the tensor's data stays valid in the
+    graph's pool; eager calls are protected by the generation tag of ops.ride_stats instead)."""
+    if torch.is_tensor(out):
+        st = getattr(out, "_nlc_stats", None)
+        if st is not None:
+            out._nlc_stats = st.clone()
+    elif isinstance(out, (tuple, list)):
+        for o in out:
+            _own_output_stats(o)
+    elif isinstance(out, dict):
+        for o in out.values():
+            _own_output_stats(o)
 
 
 class HipModule:
@@ -96,7 +115,10 @@ class HipModule:
         if arena is None:
             arena = self.__dict__["_stats_arena"] = ops.StatsArena()
         with ops.stats_scope(arena, self.device):
-            return fn(self, *args, **kwargs)
+            out = fn(self, *args, **kwargs)
+            if torch.cuda.is_current_stream_capturing():
+                _own_output_stats(out)
+            return out
 
     def _graph_call(self, fn, args, kwargs):
         self._require_gpu()
@@ -263,6 +285,7 @@ class HipModule:
         # the packed weights bake ops.ATTN_BASE2 in (log2(e) folded into the q rows): a flip re-packs
         if self._plan is not None and self.__dict__.get("_plan_base2") != ops.ATTN_BASE2:
             self._plan = None
+            self.drop_graphs()                 # graphs captured under the old value hold raw pointers into the old plan's weights
         if self._plan is None:
             self._require_gpu()
             with torch.cuda.device(self.device):

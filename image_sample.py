@@ -51,6 +51,12 @@ SYNTHETIC = {
                                    dropout=0.0, in_channels=3, resamp_with_conv=True, use_fp16=False),
                         diffusion=dict(num_diffusion_timesteps=1000, beta_schedule="linear"),
                         data=dict(dataset="CIFAR10", image_size=32, channels=3, subset_1k=False)), "celeba_hq"),
+    # a small ADM (the reference's "openai" type) in its use_fp16 mode: the file-based path's stand-in in tests/test_cli_files_gpu.py
+    "adm_tiny": (dict(model=dict(type="openai", image_size=64, num_channels=64, num_res_blocks=1, channel_mult="1,2,2,4", learn_sigma=True,
+                                 attention_resolutions="16,8", num_head_channels=32, use_scale_shift_norm=True, resblock_updown=True,
+                                 use_fp16=True, use_new_attention_order=False),
+                      diffusion=dict(num_diffusion_timesteps=1000, beta_schedule="linear"),
+                      data=dict(dataset="ImageNet", image_size=64, channels=3, subset_1k=False)), "imagenet"),
     # BASELINE config 4: CelebA-HQ-256 DDPM UNet
     "celebahq256": (dict(model=dict(type="simple", ch=128, out_ch=3, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2,
                                     attn_resolutions=[16], dropout=0.0, in_channels=3, resamp_with_conv=True, use_fp16=True),

@@ -151,7 +151,10 @@ typedef struct nlc_conv_desc {
                          /* workgroup ADDS its contributions with 64-bit integer atomics - a contribution v (an f32 partial    */
                          /* sum) as hi = floor(v), lo = floor((v - hi) 2^44); value = hi + lo 2^-44 - so the totals are exact   */
                          /* sums of the contributions in ANY arrival order: bit-reproducible.  The CALLER ZEROES the buffer    */
-                         /* before the launch (the library only adds); 16-byte aligned.  nlc_conv2d_stats_partials(desc,      */
+                         /* before the launch (the library only adds); 16-byte aligned (checked).  A contribution that is inf, */
+                         /* NaN or >= 2^45 in magnitude sets bit 62 of its chunk's sumsq.hi word instead (atomic OR; no add      */
+                         /* reaches or clears that bit): the consumers then give that chunk's groups NaN (mean, rstd), as         */
+                         /* F.group_norm does for a group holding a non-finite value.  nlc_conv2d_stats_partials(desc,          */
                          /* dtype) must be > 0 (16-bit, NHWC, Cout % 128 == 0, the LDS-halo and LDS-DMA kernels).  Consumed by */
                          /* nlc_groupnorm_prestats / _pool2x2 / _coef.                                                        */
     int32_t policy;      /* NLC_CONV_* (0 = AUTO); the three queries below honour it like nlc_conv2d does */

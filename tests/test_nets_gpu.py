@@ -132,3 +132,55 @@ def test_adm_network_with_groupnorm_in_the_conv_prologue():
         ops.FUSE_GN_CONV, ops.CONV_POLICY = was_f, was_p
     scale = ref.abs().max().item()
     assert max_err(got, ref) <= 3e-2 * scale and max_err(got, g["out"]) <= 5e-2 * g["out"].abs().max().item()
+
+
+def test_graph_outputs_own_their_ride_along_statistics():
+    """A feature map returned by a captured evaluation keeps valid GroupNorm totals after OTHER evaluations of the same module have
+    re-zeroed the module's statistics arena (hipnet._own_output_stats): encode (graph) -> forward (graph) -> forward (eager) -> the
+    sigma net on the kept feature map gives the bits of the immediate encode -> sigma order."""
+    from diffusion_nlc_amd import ops
+    g = load_npz("net_adm_tiny")
+    eps, sig = _models("adm_tiny", torch.bfloat16)
+    x, t = g["x"].to("cuda:0"), g["t"].to("cuda:0").float()
+    feat0 = eps.run(x, t, mode="encode", feat_nhwc=True)
+    r_ref = sig.run_nhwc(feat0).cpu()
+    eps.use_graphs = True
+    try:
+        feat = eps.run(x, t, mode="encode", feat_nhwc=True)
+        had = ops.ride_stats(feat)
+        kept = None if had is None else had.clone()
+        eps.run(x, t, mode="forward")                    # another graph of the same module: re-zeroes and rewrites the arena
+        eps.use_graphs = False
+        eps.run(x, t, mode="forward")                    # and an eager evaluation
+        if kept is not None:
+            assert torch.equal(ops.ride_stats(feat), kept)
+        assert torch.equal(feat, feat0)
+        r = sig.run_nhwc(feat).cpu()
+    finally:
+        eps.use_graphs = False
+        eps.drop_graphs()
+    assert torch.equal(r, r_ref)
+
+
+def test_attention_base_flip_drops_captured_graphs():
+    """ops.ATTN_BASE2 is baked into the packed q rows: a flip re-packs AND forgets the graphs that point into the old weights."""
+    from diffusion_nlc_amd import ops
+    g = load_npz("net_adm_tiny")
+    eps, _ = _models("adm_tiny", torch.bfloat16)
+    x, t = g["x"].to("cuda:0"), g["t"].to("cuda:0").float()
+    was = ops.ATTN_BASE2
+    eps.use_graphs = True
+    try:
+        a = eps.run(x, t, mode="forward").clone()
+        ops.ATTN_BASE2 = not was
+        eps.plan()
+        assert not eps.__dict__.get("_graphs")
+        b = eps.run(x, t, mode="forward").clone()
+        ops.ATTN_BASE2 = was
+        c = eps.run(x, t, mode="forward").clone()
+    finally:
+        ops.ATTN_BASE2 = was
+        eps.use_graphs = False
+        eps.drop_graphs()
+    assert torch.equal(a, c)
+    assert max_err(a.float().cpu(), b.float().cpu()) <= 5e-2 * a.float().abs().max().item()

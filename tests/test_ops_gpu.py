@@ -591,6 +591,36 @@ def test_conv_emits_groupnorm_statistics_and_groupnorm_uses_them(conv_policy, t1
     assert (fused.float().cpu() - ref).abs().max().item() <= 2e-2 * scale
 
 
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")], ids=["nan", "inf"])
+def test_non_finite_outputs_poison_the_ride_along_statistics(conv_policy, t16, bad):
+    """A convolution whose stored output holds an inf / NaN marks the chunk (bit 62 of sumsq.hi, Stat16::poison) instead of
+    converting a non-finite float to an integer; GroupNorm fed with the totals then makes exactly the groups F.group_norm makes
+    NaN - the whole group of the affected image - and leaves every other (image, group) as it was."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, W, Cout = 2, 64, 32, 32, 256
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    res = torch.zeros(B, Cout, H, W)
+    res[1, 40, 7, 9] = bad                                               # image 1, channel 40 -> group 5 of 32 (8 channels wide)
+    pw = ops.pack_conv(w, None, t16, _dev())
+    y = ops.conv2d(_nhwc(x, t16), pw, res=_nhwc(res, t16))
+    st = ops.ride_stats(y)
+    assert st is not None
+    marks = (st[..., 2] >> 62) & 1
+    want = torch.zeros_like(marks)
+    want[1, 40 // (Cout // st.shape[1])] = 1
+    assert torch.equal(marks.cpu(), want.cpu())
+    gamma, beta = torch.randn(Cout, generator=g).to(_dev()), torch.randn(Cout, generator=g).to(_dev())
+    fused = ops.groupnorm(y, gamma, beta, groups=32, eps=1e-5, silu=False).float().cpu()
+    ref = F.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, gamma.cpu(), beta.cpu(), eps=1e-5).permute(0, 2, 3, 1)
+    assert torch.equal(torch.isnan(fused), torch.isnan(ref))
+    assert torch.isnan(fused[1, :, :, 40:48]).all() and not torch.isnan(fused[0]).any()
+    ok = ~torch.isnan(ref)
+    assert (fused[ok] - ref[ok]).abs().max().item() <= _tol(t16) * ref[ok].abs().max().item()
+
+
 STAT_CASES = [
     # (B, Cin, H, W, Cout, expected partials per image under the production dispatch, what emits them)
     (2, 512, 16, 16, 256, 256, "split-K (last arriver): one partial per pixel"),
