@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NLC_HIP_LIB", _HERE / "libnlc_hip.so"))     # override: kernel A/B experiments only
 BUILD_SCRIPT = _HERE / "csrc" / "build.sh"
 
-ABI_VERSION = 6                 # NLC_ABI_VERSION of include/nlc_hip.h
+ABI_VERSION = 7                 # NLC_ABI_VERSION of include/nlc_hip.h
 NLC_F32, NLC_BF16, NLC_F16 = 0, 1, 2
 MATH_NATIVE, MATH_F16X3 = 0, 1      # nlc_conv_desc.math / nlc_pack_conv_weights_ex
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
@@ -38,6 +38,20 @@ class NlcError(RuntimeError):
 
 
 NLC_EINVAL, NLC_ELAUNCH, NLC_EUNSUPPORTED = -1, -2, -3
+
+
+class GnIn(C.Structure):
+    """nlc_gn_in: GroupNorm (+FiLM) (+SiLU) of a convolution's input, from the ride-along totals of its producers."""
+    _fields_ = [
+        ("stats0", C.c_void_p), ("stats1", C.c_void_p),
+        ("granule0", C.c_int32), ("granule1", C.c_int32),
+        ("groups", C.c_int32),
+        ("eps", C.c_float),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("ss_stride", C.c_int32),
+        ("act", C.c_int32),
+    ]
 
 
 class ConvDesc(C.Structure):
@@ -73,6 +87,7 @@ class ConvDesc(C.Structure):
         ("debug", C.c_int32),
         ("w_scale", C.c_void_p),
         ("norm_out", C.c_void_p),
+        ("gn_in", C.POINTER(GnIn)),
     ]
 
 
@@ -116,6 +131,7 @@ SIGNATURES = {
     "nlc_conv2d_stats_partials": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_prologue_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_norm_out_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
+    "nlc_conv2d_gn_in_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_groupnorm_coef": (C.c_int, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "nlc_conv_first_stats_partials": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),

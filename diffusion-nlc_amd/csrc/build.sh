@@ -5,7 +5,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 root="$(cd "$here/../.." && pwd)"
 out="$here/../libnlc_hip.so"
 mkdir -p "$here/obj"
-srcs="abi pack conv_igemm conv_fast conv_halo conv_narrow conv_pw groupnorm attention elementwise sampler edm constraint"
+srcs="abi pack conv_igemm conv_fast conv_halo conv_narrow conv_small conv_pw groupnorm attention elementwise sampler edm constraint"
 # objects of sources that no longer exist would be linked in: drop them
 for o in "$here"/obj/*.o; do
   [ -e "$o" ] || continue
@@ -15,7 +15,7 @@ done
 pids=()
 for f in $srcs; do
   o="$here/obj/$f.o"
-  if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/conv_params.h" -nt "$o" ] || [ "$root/include/nlc_hip.h" -nt "$o" ] || [ "$here/build.sh" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/common.h" -nt "$o" ] || [ "$here/conv_params.h" -nt "$o" ] || [ "$here/conv_small.h" -nt "$o" ] || [ "$root/include/nlc_hip.h" -nt "$o" ] || [ "$here/build.sh" -nt "$o" ]; then
     extra=""
     # the sampler kernels restate the reference's f32 algebra op by op: no FMA contraction there
     # (sqrt(s^2 - sqrt(s^2)^2) must be exactly 0, src/schedulers.py:445-446)

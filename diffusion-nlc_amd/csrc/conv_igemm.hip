@@ -21,6 +21,7 @@
 //         with the same k permutation on both operands.
 #include "common.h"
 #include "conv_params.h"
+#include "conv_small.h"
 #include <cstring>
 #include <stdlib.h>
 
@@ -277,10 +278,48 @@ static bool desc_sane(const nlc_conv_desc* d, int dtype) {
     return d && nlc_dtype_ok(dtype) && d->B > 0 && d->Hout > 0 && d->Wout > 0 && d->Cout > 0 && d->policy != NLC_CONV_GENERIC;
 }
 
+// The small-map 3x3 kernel (conv_small.hip) takes a launch when the caller asks for it - a GroupNorm of the input to apply on the way
+// into LDS (nlc_conv_desc.gn_in) or policy NLC_CONV_FORCE_SMALL - and the geometry fits; tuning bit 21 = never (A/B).
+static bool small_wanted(const nlc_conv_desc* d, const KParams& p, int dtype, SmallGeom& g) {
+    if (!(d->gn_in || d->policy == NLC_CONV_FORCE_SMALL) || (d->tuning & (1 << 21))) return false;
+    return nlc_conv_small_geom(p, dtype, g);
+}
+
+extern "C" int nlc_conv2d_gn_in_supported(const nlc_conv_desc* d, int dtype) {
+    if (!desc_sane(d, dtype) || (d->tuning & (1 << 21))) return 0;
+    KParams p{};
+    fill_params(d, p);
+    SmallGeom g;
+    return nlc_conv_small_geom(p, dtype, g) ? 1 : 0;
+}
+
+// nlc_gn_in -> the kernel's view (validated)
+static int fill_gn_in(const nlc_gn_in* q, const KParams& p, GnIn& g) {
+    const int g0 = q->granule0 == 4 ? 4 : 8, g1 = q->granule1 == 4 ? 4 : 8;
+    NLC_REQUIRE((q->granule0 == 0 || q->granule0 == 4 || q->granule0 == 8) && (q->granule1 == 0 || q->granule1 == 4 || q->granule1 == 8),
+                "nlc_conv2d: gn_in granules must be 0 (= 8), 4 or 8");
+    NLC_REQUIRE(q->stats0 && (p.C1 == 0) == (q->stats1 == nullptr), "nlc_conv2d: gn_in stats0 / stats1 must match x0 / x1");
+    NLC_REQUIRE(q->groups > 0 && p.Ctot % q->groups == 0, "nlc_conv2d: gn_in groups=%d must divide C0+C1=%d", q->groups, p.Ctot);
+    const int gs = p.Ctot / q->groups;
+    NLC_REQUIRE(gs % g0 == 0 && (p.C1 == 0 || gs % g1 == 0), "nlc_conv2d: gn_in group size %d must be a multiple of the statistics granules (%d, %d)", gs, g0, g1);
+    NLC_REQUIRE((q->scale == nullptr) == (q->shift == nullptr), "nlc_conv2d: gn_in scale / shift must come together");
+    NLC_REQUIRE(!q->scale || q->ss_stride >= p.Ctot, "nlc_conv2d: gn_in ss_stride < C0+C1");
+    NLC_REQUIRE(q->act == NLC_ACT_NONE || q->act == NLC_ACT_SILU, "nlc_conv2d: bad gn_in act %d", q->act);
+    NLC_REQUIRE(((reinterpret_cast<uintptr_t>(q->stats0) | reinterpret_cast<uintptr_t>(q->stats1)) & 15) == 0, "nlc_conv2d: gn_in statistics must be 16-byte aligned");
+    g.tot0 = (const long long*)q->stats0; g.tot1 = (const long long*)q->stats1;
+    g.tsh0 = g0 == 4 ? 2 : 3; g.tsh1 = g1 == 4 ? 2 : 3;
+    g.C0 = p.C0; g.C1 = p.C1; g.gs = gs;
+    g.invN = 1.0 / ((double)p.Hin * p.Win * gs);
+    g.eps = q->eps; g.gamma = q->gamma; g.beta = q->beta; g.scale = q->scale; g.shift = q->shift; g.ss_stride = q->ss_stride;
+    g.act = q->act; g.div_gs = FastDiv::make(gs);
+    return NLC_OK;
+}
+
 extern "C" int64_t nlc_conv2d_workspace_bytes(const nlc_conv_desc* d, int dtype) {
     if (!desc_sane(d, dtype)) return 0;
     KParams p{};
     fill_params(d, p);
+    { SmallGeom sg; if (small_wanted(d, p, dtype, sg)) return nlc_conv_small_split_bytes(p, sg); }
     if (nlc_conv_narrow_ok(p, dtype)) return 0;
     const int64_t M64 = (int64_t)d->B * d->Hout * d->Wout;
     const int ks = nlc_conv_halo_ksplit(p, dtype);
@@ -397,7 +436,7 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(M64 < (1ll << 31) - BM, "nlc_conv2d: too many output pixels");
     NLC_REQUIRE(!d->res_upsample2x || (d->res && d->Hout % 2 == 0 && d->Wout % 2 == 0), "nlc_conv2d: res_upsample2x needs a residual and even Hout, Wout");
     NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
-    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_GENERIC, "nlc_conv2d: bad policy %d", d->policy);
+    NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_SMALL, "nlc_conv2d: bad policy %d", d->policy);
     NLC_REQUIRE(d->stats_granule == 0 || d->stats_granule == 4 || d->stats_granule == 8, "nlc_conv2d: stats_granule must be 0 (= 8), 4 or 8");
 
     if ((d->debug & 2) && d->math == NLC_MATH_F16X3) { const int cr = check_x3_domain(d, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
@@ -406,6 +445,26 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     // stride-1 3x3 / 1x1 "same" convolutions take the LDS-DMA fast path; everything else (strided,
     // odd kernels, cropped outputs) the generic gather kernel.  policy NLC_CONV_GENERIC forces the latter (A/B runs).
     const bool force_generic = d->policy == NLC_CONV_GENERIC;
+    {
+        SmallParams sp{};
+        if (small_wanted(d, p, dtype, sp.geo)) {
+            sp.k = p;
+            if (d->gn_in) { const int gr = fill_gn_in(d->gn_in, p, sp.gn); if (gr != NLC_OK) return gr; }
+            if (d->stats_out) {
+                NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * (p.Cout / p.stats_gran) * 4 * (int64_t)sizeof(long long), "nlc_conv2d: stats_out too small");
+                NLC_REQUIRE((reinterpret_cast<uintptr_t>(d->stats_out) & 15) == 0, "nlc_conv2d: stats_out must be 16-byte aligned (its consumers read 16-byte pairs)");
+                sp.k.stats = (long long*)d->stats_out;
+            }
+            if (sp.geo.ks > 1) {
+                NLC_REQUIRE(d->workspace && d->workspace_bytes >= nlc_conv_small_split_bytes(p, sp.geo),
+                            "nlc_conv2d: this small-map launch splits K %d ways: it needs the workspace of nlc_conv2d_workspace_bytes", sp.geo.ks);
+                sp.k.partial = (float*)d->workspace;
+                if (d->debug & 1) { const int cr = check_counters(sp.k, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
+            }
+            return nlc_conv_small_dispatch(sp, dtype, (hipStream_t)stream);
+        }
+        NLC_REQUIRE(!d->gn_in, "nlc_conv2d: gn_in given but this launch cannot apply it (ask nlc_conv2d_gn_in_supported first)");
+    }
     if (!force_generic) {
         int Pfast = 0;
         if (d->stats_out) {

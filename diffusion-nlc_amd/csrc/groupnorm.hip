@@ -294,33 +294,10 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(const GNParams p, float
     }
 }
 
-// (mean, rstd) of group g of image b from the totals that rode along with the producing convolutions (GNParams::tot0 / tot1): the
-// group's chunks - over both sources of a concatenated input; a group is a whole number of chunks of either source (host-checked) -
-// added in f64 (value = hi + lo * 2^-44: exact integers, so no order dependence upstream), var = E[x^2] - mean^2 in f64.
-// Every apply thread evaluates this for the one or two groups its channels lie in: 1 ... 8 32-byte loads - there is no partials
-// array, no reduction pass and no finalize launch between a convolution and the normalisation that follows it.
+// (mean, rstd) of a group from the ride-along totals: conv_params.h, gn_group_from_totals_t (shared with conv_small.hip, which
+// applies the same normalisation on its input's way into LDS)
 __device__ __forceinline__ void gn_group_from_totals(const GNParams& p, int b, int g, float& mean, float& rstd) {
-    double S = 0.0, Q = 0.0;
-    long long marks = 0;             // bit 62 of a chunk's sumsq.hi word: a contribution was inf / NaN / out of the limbs' domain (Stat16::poison)
-    const int ch = g * p.gs, ch1 = ch + p.gs;
-    auto add = [&](const long long* tot, int nq, int first_chunk, int nchunk) {      // the group's chunks of one source are contiguous
-        const longlong2* t = reinterpret_cast<const longlong2*>(tot + ((int64_t)b * nq + first_chunk) * 4);
-        for (int k = 0; k < nchunk; ++k) {
-            const longlong2 ts = t[2 * k], tq = t[2 * k + 1];
-            S += (double)ts.x + (double)ts.y * (1.0 / Stat16::LIMB);
-            Q += (double)tq.x + (double)tq.y * (1.0 / Stat16::LIMB);
-            marks |= tq.x;
-        }
-    };
-    const int e0 = min(ch1, p.C0), s1 = max(ch, p.C0);
-    if (ch < e0) add(p.tot0, p.C0 >> p.tsh0, ch >> p.tsh0, (e0 - ch) >> p.tsh0);
-    if (s1 < ch1) add(p.tot1, p.C1 >> p.tsh1, (s1 - p.C0) >> p.tsh1, (ch1 - s1) >> p.tsh1);
-    const double mean_d = S * p.invN;
-    double var = Q * p.invN - mean_d * mean_d;          // f64: E[x^2] - mean^2 keeps ~9 digits after the cancellation
-    if (var < 0.0) var = 0.0;
-    mean = (float)mean_d;
-    rstd = rsqrtf((float)(var + (double)p.eps));         // (the totals describe 16-bit tensors: a 1-ulp f32 reciprocal square root is ample)
-    if (marks & (long long)Stat16::POISON) mean = rstd = __builtin_nanf("");
+    gn_group_from_totals_t(p, b, g, mean, rstd);
 }
 
 // nlc_groupnorm_coef: the (a, b) table of GroupNorm (+FiLM) per (image, channel) from the totals, for a convolution that applies the

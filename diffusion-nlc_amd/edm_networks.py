@@ -78,13 +78,15 @@ class _UNetBlock:
         both = None
         if self.skip is not None and not self.down and not self.up:
             both = self.n0.with_skip(x, self.skip, silu=True, x1=x1)                # norm0 and the skip projection from one read
-        h, res = both if both is not None else (self.n0(x, silu=True, x1=x1), None)
-        if self.down:
-            h = ops.avgpool2x2(h)
         emb = None if self.emb_off is None else emb_all[:, self.emb_off:]
-        h = ops.conv2d(h, self.c0, upsample2x=self.up, emb=emb)
-        if not self.pure:
-            h = self.n1(h, silu=True)
+        res = None
+        if both is not None:
+            hn, res = both
+            h = ops.conv2d(hn, self.c0, emb=emb)
+        elif self.down:
+            h = ops.conv2d(ops.avgpool2x2(self.n0(x, silu=True, x1=x1)), self.c0, emb=emb)
+        else:                              # (small maps: the normalisation is applied by the convolution itself, hipnet.Norm.then_conv)
+            h = self.n0.then_conv(x, self.c0, silu=True, x1=x1, upsample2x=self.up, emb=emb)
         # PureUNetBlock.forward feeds conv0's output straight into conv1 (src/edm_networks.py:944-945)
         if res is not None:
             pass
@@ -95,7 +97,10 @@ class _UNetBlock:
             res = ops.conv2d(xs, self.skip, x1=xs1, upsample2x=self.up)
         else:
             res = x
-        x = ops.conv2d(h, self.c1, res=res, out_scale=SKIP_SCALE)
+        if self.pure:
+            x = ops.conv2d(h, self.c1, res=res, out_scale=SKIP_SCALE)
+        else:
+            x = self.n1.then_conv(h, self.c1, silu=True, res=res, out_scale=SKIP_SCALE)
         if self.attn is not None:
             norm, qkv, proj = self.attn
             B, H, W, C = x.shape

@@ -340,6 +340,11 @@ class Norm:
     def then_conv(self, x, pw, *, silu: bool, x1=None, scale=None, shift=None, **conv_kw):
         """conv(act(norm(cat(x, x1)))) - with the normalisation applied inside the convolution's LDS prologue when the launch
         supports it and the statistics rode along with x (x1), else as the separate GroupNorm pass followed by the conv."""
+        geom = {k: v for k, v in conv_kw.items() if k in ("stride", "pad", "out_hw", "upsample2x", "out_nchw_f32", "res_upsample2x")}
+        if ops.FUSE_GN_SMALL and not geom.get("res_upsample2x") and not geom.get("upsample2x") and ops.conv2d(x, pw, x1=x1, query_gn_in=True, **geom):
+            spec = ops.gn_in_spec(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, silu=silu, x1=x1, scale=scale, shift=shift)
+            if spec is not None:
+                return ops.conv2d(x, pw, x1=x1, gn_in=spec, **conv_kw)
         if ops.FUSE_GN_CONV and ops.conv2d(x, pw, x1=x1, query_prologue=True, **{k: v for k, v in conv_kw.items() if k in ("stride", "pad", "out_hw", "upsample2x", "out_nchw_f32")}):
             coef = ops.groupnorm_coef(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, x1=x1, scale=scale, shift=shift)
             if coef is not None:

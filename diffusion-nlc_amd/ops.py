@@ -148,7 +148,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.d
 CONV_PROFILE = None
 # Kernel-selection policy handed to every nlc_conv2d call (nlc_conv_desc.policy): "auto" is the production dispatch;
 # tests and A/B tools pin a kernel with "halo" (LDS-halo kernel for every eligible shape), "no_halo" or "generic".
-CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3}
+CONV_POLICIES = {"auto": 0, "halo": 1, "no_halo": 2, "generic": 3, "small": 4}
 CONV_POLICY = "auto"
 CONV_TUNING = 0              # nlc_conv_desc.tuning: schedule A/B switches for tools/ (0 in production)
 CONV_DEBUG = 0               # nlc_conv_desc.debug: bit 0 = verify the split-K arrival counters before every split launch; bit 1 = verify
@@ -262,7 +262,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
            act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True,
            emit_stats: bool = True, allow_split: bool = False, gn_coef: Optional[torch.Tensor] = None,
            gn_act: int = ACT_NONE, query_prologue: bool = False, res_upsample2x: bool = False,
-           norm_out: bool = False, query_norm_out: bool = False):
+           norm_out: bool = False, query_norm_out: bool = False, gn_in=None, query_gn_in: bool = False):
     """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1).
     ``emit_stats``: let the epilogue also write the GroupNorm statistics of the output when the launch supports it
     (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass.
@@ -275,7 +275,10 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
     up-sampling ResBlock, src/unet_adm.py:186-190) - read in place, no upsampled copy in HBM.
     ``norm_out`` (with ``gn_coef`` / ``gn_act``): a pointwise launch also writes gn_act(GroupNorm(cat(x0, x1))) - the convolution itself
     runs on the input as given - and ``(out, normalised)`` is returned: a ResBlock's skip projection and the GroupNorm + SiLU in front
-    of its first 3x3 from one read of the input.  ``query_norm_out=True`` only asks whether this launch could (bool)."""
+    of its first 3x3 from one read of the input.  ``query_norm_out=True`` only asks whether this launch could (bool).
+    ``gn_in`` (from ``gn_in_spec``): the GroupNorm (+FiLM) (+SiLU) in front of this convolution, applied by the small-map 3x3 kernel on the
+    input's way into LDS from the totals that rode along with x0 / x1 - no normalisation launch, no normalised tensor in HBM;
+    ``query_gn_in=True`` only asks whether this launch could (bool)."""
     lib = _ext.load()
     dt = pw.dtype
     linear = x0.dim() == 2
@@ -299,10 +302,6 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         Wout = (WL + 2 * pad[1] - pw.KW) // stride + 1
     else:
         Hout, Wout = out_hw
-    if out_nchw_f32:
-        out = torch.empty(B, pw.Cout, Hout, Wout, device=x0.device, dtype=torch.float32)
-    else:
-        out = torch.empty(B, Hout, Wout, pw.Cout, device=x0.device, dtype=dt)
     if res is not None:
         _need(res, dt, "conv2d res")
         if res_upsample2x and (Hout % 2 or Wout % 2):
@@ -323,13 +322,22 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
                  Cout=pw.Cout, KH=pw.KH, KW=pw.KW, stride=stride, pad_t=pad[0], pad_l=pad[1],
                  upsample2x=1 if upsample2x else 0, w=pw.w.data_ptr(), Cin_pad=pw.Cin_pad, Cout_pad=pw.Cout_pad,
                  bias=_ptr(pw.bias) if use_bias else None, emb=_ptr(emb), emb_stride=emb_stride, res=_ptr(res),
-                 out_scale=out_scale, act=act, out=out.data_ptr(),
+                 out_scale=out_scale, act=act, out=None,
                  out_mode=OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC, policy=CONV_POLICIES[CONV_POLICY], tuning=CONV_TUNING,
                  res_upsample2x=1 if res_upsample2x else 0, math=pw.math, debug=CONV_DEBUG, w_scale=_ptr(pw.w_scale))
     if query_prologue:
         return bool(lib.nlc_conv2d_prologue_supported(C.byref(d), dtype_enum(dt)))
     if query_norm_out:
         return bool(lib.nlc_conv2d_norm_out_supported(C.byref(d), dtype_enum(dt)))
+    if query_gn_in:
+        return bool(lib.nlc_conv2d_gn_in_supported(C.byref(d), dtype_enum(dt)))
+    if out_nchw_f32:
+        out = torch.empty(B, pw.Cout, Hout, Wout, device=x0.device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, Hout, Wout, pw.Cout, device=x0.device, dtype=dt)
+    d.out = out.data_ptr()
+    if gn_in is not None:
+        d.gn_in = C.pointer(gn_in[0])              # (gn_in[1:] keeps the tensors it points into alive until the launch is queued)
     hn = None
     if norm_out:
         if gn_coef is None:
@@ -396,10 +404,46 @@ def reset_conv_workspaces() -> None:
     WS_GENERATION += 1
 
 
+def gn_in_spec(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], *, groups: int, eps: float, silu: bool,
+               x1: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None):
+    """(nlc_gn_in, keep-alive...) for conv2d(gn_in=...): GroupNorm (+FiLM) (+SiLU) over cat(x0, x1) described by the totals that rode
+    along with the producing convolutions, or None when they are not available (f32 models, inputs without attached statistics,
+    group sizes that the totals' chunks cannot express): the caller then runs groupnorm()."""
+    if not FUSED_GN_STATS or not is16(x0.dtype):
+        return None
+    C0 = x0.shape[-1]
+    C1 = 0 if x1 is None else x1.shape[-1]
+    Ctot = C0 + C1
+    if C0 % 8 or C1 % 8 or Ctot % groups:
+        return None
+    s0, s1 = ride_stats(x0), ride_stats(x1)
+    if s0 is None or (x1 is not None and s1 is None):
+        return None
+    g0 = _stats_gran_of(x0, s0)
+    g1 = _stats_gran_of(x1, s1) if s1 is not None else 8
+    gs = Ctot // groups
+    if gs % g0 or (x1 is not None and gs % g1):
+        return None
+    ss_stride = 0
+    if scale is not None:
+        ss_stride = scale.stride(0)
+        if shift is None or shift.stride(0) != ss_stride or scale.stride(1) != 1 or shift.stride(1) != 1 or scale.dtype != torch.float32:
+            raise ValueError("gn_in_spec: scale/shift must be row-strided f32 views sharing a row stride")
+    spec = _ext.GnIn(stats0=s0.data_ptr(), stats1=_ptr(s1), granule0=g0, granule1=g1, groups=groups, eps=eps, gamma=_ptr(gamma),
+                     beta=_ptr(beta), scale=_ptr(scale), shift=_ptr(shift), ss_stride=ss_stride, act=ACT_SILU if silu else ACT_NONE)
+    return (spec, s0, s1, gamma, beta, scale, shift)
+
+
+# networks: on the small maps (8 / 16 / 32 pixels wide) the GroupNorm (+FiLM) + SiLU in front of a ResBlock's 3x3 convolutions is applied
+# by the convolution itself on the input's way into LDS (nlc_conv_desc.gn_in, conv_small.hip) instead of by a launch of its own
+FUSE_GN_SMALL = True
+
+
 def config_key() -> tuple:
     """Every module-level switch that changes which kernels / layouts a network evaluation launches.  HipModule keys its captured
     hipGraphs by it (a graph bakes the configuration it was captured under); setters of these switches need no other hook."""
-    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_POOL, FUSE_GN_SKIP, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2, WS_GENERATION)
+    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_POOL, FUSE_GN_SKIP, FUSE_GN_SMALL, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2,
+            WS_GENERATION)
 
 
 def conv_first(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype,

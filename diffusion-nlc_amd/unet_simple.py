@@ -51,13 +51,15 @@ class _ResnetBlock:
 
     def __call__(self, x, x1, emb_all):
         both = self.n1.with_skip(x, self.nin, silu=True, x1=x1) if self.nin is not None else None      # norm1 and nin_shortcut: one read
-        h, res = both if both is not None else (self.n1(x, silu=True, x1=x1), None)
         emb = None if self.emb_off is None else emb_all[:, self.emb_off:]
-        h = ops.conv2d(h, self.c1, emb=emb)
-        h = self.n2(h, silu=True)
+        if both is not None:
+            hn, res = both
+            h = ops.conv2d(hn, self.c1, emb=emb)
+        else:                              # (small maps: the normalisation is applied by the convolution itself, hipnet.Norm.then_conv)
+            h, res = self.n1.then_conv(x, self.c1, silu=True, x1=x1, emb=emb), None
         if res is None:
             res = ops.conv2d(x, self.nin, x1=x1) if self.nin is not None else x
-        return ops.conv2d(h, self.c2, res=res)
+        return self.n2.then_conv(h, self.c2, silu=True, res=res)
 
 
 class _AttnBlock:

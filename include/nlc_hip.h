@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NLC_ABI_VERSION 6
+#define NLC_ABI_VERSION 7
 
 enum { NLC_F32 = 0, NLC_BF16 = 1, NLC_F16 = 2 };
 /* matrix arithmetic of nlc_conv2d on NLC_F32 tensors (nlc_conv_desc.math; weights must be packed for the same mode):
@@ -70,7 +70,8 @@ enum { NLC_VAR_NONE = 0, NLC_VAR_FIXEDSMALL = 1, NLC_VAR_FIXEDLARGE = 2, NLC_VAR
  * LDS-halo kernel for stride-1 3x3 "same" convolutions with >= 128 (16x16 pixel x 128 channel) tiles, else the LDS-DMA
  * implicit-GEMM kernel (3x3 / 1x1), else the generic gather kernel.  The others exist so that parity tests and A/B
  * timings can pin a kernel per call; there is no process-wide switch. */
-enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3 };
+enum { NLC_CONV_AUTO = 0, NLC_CONV_FORCE_HALO = 1, NLC_CONV_NO_HALO = 2, NLC_CONV_GENERIC = 3,
+       NLC_CONV_FORCE_SMALL = 4 }; /* the small-map 3x3 kernel (conv_small.hip) for every shape it takes, with or without gn_in */
 
 int nlc_version(void);
 const char* nlc_last_error(void);
@@ -121,6 +122,25 @@ int nlc_pack_conv_weights_ex(const float* w, const float* bias, int Cout, int Ci
  * Input may be the channel-concatenation of two NHWC tensors (th.cat at unet_adm.py:662)
  * and may be read through a nearest-neighbour 2x upsample (F.interpolate, unet_adm.py:107).
  * ---------------------------------------------------------------------------------- */
+/* GroupNorm (+FiLM) (+SiLU) of a convolution's INPUT, described by the ride-along totals of the launches that produced the input
+ * (nlc_conv_desc.gn_in, ABI v7): the small-map 3x3 kernel normalises its input slice on the way into LDS, so the GroupNorm + SiLU in
+ * front of a ResBlock's convolutions (/root/reference/src/unet_adm.py:182-185,206-211,248-252; src/unet_simple.py:117-124;
+ * src/edm_networks.py:185-192) costs neither a launch nor a pass over HBM.  Same arithmetic as nlc_groupnorm_prestats:
+ *   y = act( ((x - mean) * rstd * gamma + beta) * (1 + scale[b][c]) + shift[b][c] ),   zero padding stays zero.
+ * Fields as in nlc_groupnorm_prestats: stats0 / stats1 = int64 [B][C0/g0 | C1/g1][4] totals of x0 / x1 (stats1 NULL iff C1 == 0),
+ * granule 0 | 8 | 4; (C0+C1)/groups a multiple of both granules; gamma / beta f32 [C0+C1] or NULL; scale / shift f32 row-strided
+ * [B][>= C0+C1] views (both or neither); act = NLC_ACT_NONE | NLC_ACT_SILU. */
+typedef struct nlc_gn_in {
+    const void* stats0; const void* stats1;
+    int32_t granule0, granule1;
+    int32_t groups;
+    float eps;
+    const float* gamma; const float* beta;
+    const float* scale; const float* shift;
+    int32_t ss_stride;
+    int32_t act;
+} nlc_gn_in;
+
 typedef struct nlc_conv_desc {
     const void* x0;      /* [B][Hin][Win][C0]                                   */
     const void* x1;      /* [B][Hin][Win][C1] or NULL; logical input = cat(x0,x1)*/
@@ -187,6 +207,10 @@ typedef struct nlc_conv_desc {
                          /* front of its first 3x3 from ONE read of cat(x0, x1) (/root/reference/src/unet_adm.py:236-256: in_layers(x)      */
                          /* and skip_connection(x)).  Only launches for which nlc_conv2d_norm_out_supported(desc, dtype) returns 1          */
                          /* (16-bit, C0 and C1 multiples of 128, C0+C1 <= 512, maps of whole multiples of 64 pixels, >= 1536 output tiles). */
+    const nlc_gn_in* gn_in; /* NULL, or (ABI v7) the normalisation of the input, applied by the convolution itself on the input's way into  */
+                         /* LDS (see nlc_gn_in).  Only launches for which nlc_conv2d_gn_in_supported(desc, dtype) returns 1: 16-bit 3x3 /    */
+                         /* stride 1 / pad 1 on 8-, 16- or 32-pixel-wide maps, whole 128-pixel x 128-channel tiles, C0 and C0+C1 multiples */
+                         /* of 64.  Split-K needs the workspace of nlc_conv2d_workspace_bytes (same layout as for the other kernels).   */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
@@ -201,6 +225,10 @@ int nlc_conv2d_stats_partials(const nlc_conv_desc* d, int dtype);
 int nlc_conv2d_prologue_supported(const nlc_conv_desc* d, int dtype);
 /* 1 if nlc_conv2d would honour desc->norm_out for this descriptor (norm_out / gn_coef themselves are not looked at), else 0 */
 int nlc_conv2d_norm_out_supported(const nlc_conv_desc* d, int dtype);
+/* 1 if nlc_conv2d would honour desc->gn_in for this descriptor (the small-map 3x3 kernel takes it; gn_in itself is not looked at),
+ * else 0: the caller then runs nlc_groupnorm(_prestats) as a separate pass.  nlc_conv2d_workspace_bytes / _stats_partials answer for
+ * the kernel that WILL run: set desc->gn_in (or policy NLC_CONV_FORCE_SMALL) before asking them. */
+int nlc_conv2d_gn_in_supported(const nlc_conv_desc* d, int dtype);
 
 /* First-layer convolution for tiny Cin (<=4): reads the sampler state in the reference's
  * own layout (NCHW f32), applies the per-sample input scale c_in[b] (convert_coordinate,

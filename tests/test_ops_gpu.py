@@ -1309,3 +1309,117 @@ def test_conv2d_pointwise_with_normalised_side_output(case, t16):
     # a launch the resident pointwise kernel does not take must say so
     small = _nhwc(torch.randn(1, 64, 32, 32, generator=g), t16)
     assert not ops.conv2d(small, ops.pack_conv(torch.randn(128, 64, 1, 1, generator=g), None, t16, _dev()), query_norm_out=True)
+
+
+SMALL_CASES = [
+    # 3x3 / stride 1 / pad 1 on small maps: what conv_small.hip takes (whole 128-pixel x 128-channel tiles, 64-channel blocks)
+    dict(B=4, C0=128, H=8, W=8, Cout=128, groups=16),                                   # one block per slice, two splits, 2 images per tile
+    dict(B=2, C0=256, H=16, W=16, Cout=256, groups=32, emb=True, res=True),               # half an image per tile, FiLM
+    dict(B=1, C0=128, C1=256, H=32, W=32, Cout=128, groups=8, film=True),                 # concatenated input, 48-channel groups straddling the sources
+    dict(B=2, C0=256, C1=128, H=8, W=16, Cout=128, groups=8, res=True, act=True),         # non-square map, 8 rows x 16
+    dict(B=16, C0=512, H=8, W=8, Cout=1024, groups=32, film=True, res=False),             # two blocks per slice (256 workgroups)
+    dict(B=16, C0=1024, H=8, W=8, Cout=1024, groups=32, film=True, res=True),             # four blocks per slice: ADM-256's 8x8 level
+]
+
+
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+@pytest.mark.parametrize("case", SMALL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_small_map_conv_applies_the_groupnorm_of_its_input(case, t16):
+    """nlc_conv_desc.gn_in (conv_small.hip): conv3x3(act(GroupNorm(cat(x0, x1)) (FiLM))) in ONE launch, the normalisation applied to
+    the input slice on its way into LDS from the totals that rode along with the producers of x0 / x1 - against (i) the f32 reference
+    on the stored 16-bit inputs, (ii) the separate nlc_groupnorm_prestats + nlc_conv2d launches (same arithmetic up to the f32
+    summation order of the split), (iii) its own ride-along statistics against the stored output; deterministic."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(_seed(case))
+    B, C0, H, W, Cout, groups = (case[k] for k in ("B", "C0", "H", "W", "Cout", "groups"))
+    C1 = case.get("C1", 0)
+    Cin = C0 + C1
+    # the inputs are themselves convolution outputs (1x1, so that they carry ride-along totals), with a non-zero mean
+    def producer(c):
+        z = torch.randn(B, 64, H, W, generator=g)
+        wz = torch.randn(c, 64, 1, 1, generator=g) / 8.0
+        bz = torch.randn(c, generator=g) * 0.5 + 0.3
+        return ops.conv2d(_nhwc(z, t16), ops.pack_conv(wz, bz, t16, _dev()))
+    x0 = producer(C0)
+    x1 = producer(C1) if C1 else None
+    assert ops.ride_stats(x0) is not None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    film = case.get("film")
+    ss = (torch.randn(B, 2 * Cin + 16, generator=g) * 0.3).to(_dev()) if film else None
+    scale, shift = (ss[:, :Cin], ss[:, Cin:2 * Cin]) if film else (None, None)
+    emb = (torch.randn(B, Cout + 16, generator=g)).to(_dev()) if case.get("emb") else None
+    res = torch.randn(B, Cout, H, W, generator=g) if case.get("res") else None
+    pw = ops.pack_conv(w, b, t16, _dev())
+    kw = dict(x1=x1, emb=None if emb is None else emb[:, :Cout], res=None if res is None else _nhwc(res, t16),
+              act=1 if case.get("act") else 0)
+    gd, bd = gamma.to(_dev()), beta.to(_dev())
+    # (ii) separate launches
+    hn = ops.groupnorm(x0, gd, bd, groups=groups, eps=1e-5, silu=True, x1=x1, scale=scale, shift=shift)
+    sep = ops.conv2d(hn, pw, **{k: v for k, v in kw.items() if k != "x1"})
+    # the fused launch
+    assert ops.conv2d(x0, pw, x1=x1, query_gn_in=True)
+    spec = ops.gn_in_spec(x0, gd, bd, groups=groups, eps=1e-5, silu=True, x1=x1, scale=scale, shift=shift)
+    assert spec is not None
+    got = ops.conv2d(x0, pw, gn_in=spec, **kw)
+    again = ops.conv2d(x0, pw, gn_in=spec, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
+    # (i) f32 reference from the stored inputs
+    xc = torch.cat([x0.float().cpu()] + ([x1.float().cpu()] if C1 else []), dim=-1).permute(0, 3, 1, 2)
+    y = F.group_norm(xc, groups, gamma, beta, eps=1e-5)
+    if film:
+        y = y * (1 + scale.cpu()[:, :, None, None]) + shift.cpu()[:, :, None, None]
+    y = _rt(F.silu(y), t16)
+    ref = F.conv2d(y, _rt(w, t16), b, padding=1)
+    if emb is not None:
+        ref = ref + emb.cpu()[:, :Cout, None, None]
+    if res is not None:
+        ref = ref + _rt(res, t16)
+    if case.get("act"):
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    _close(got, ref, _tol(t16), "fused GroupNorm + conv3x3 vs f32 reference")
+    scale_ = ref.abs().max().item()
+    assert (got.float() - sep.float()).abs().max().item() <= 1.5 * _tol(t16) * scale_          # two roundings of the normalised tensor apart at most
+    # (iii) the output's own ride-along totals
+    st = ops.ride_stats(got)
+    assert st is not None
+    gran = Cout // st.shape[1]
+    ch = got.float().cpu().view(B, H * W, Cout // gran, gran)
+    tot = _totals(st)
+    rs, rq = ch.double().sum(dim=(1, 3)), (ch.double() ** 2).sum(dim=(1, 3))
+    assert (tot[..., 0] - rs).abs().max() <= 2e-3 * rs.abs().max().clamp(min=1.0)
+    assert ((tot[..., 1] - rq) / rq).abs().max() < 2e-3
+    # schedule variants: 128-pixel tiles only (tuning bit 22), and with the last arriver reducing alone instead of the distributed
+    # reduction (bit 23) - the two reductions add the same partial sums in the same order: bit-identical
+    old_t = ops.CONV_TUNING
+    try:
+        ops.CONV_TUNING = 1 << 22
+        t128 = ops.conv2d(x0, pw, gn_in=spec, **kw)
+        ops.CONV_TUNING = (1 << 22) | (1 << 23)
+        t128_last = ops.conv2d(x0, pw, gn_in=spec, **kw)
+        ops.CONV_TUNING = (1 << 22) | (1 << 23) | 1024
+        t128_fenced = ops.conv2d(x0, pw, gn_in=spec, **kw)
+    finally:
+        ops.CONV_TUNING = old_t
+    assert torch.equal(t128, t128_last) and torch.equal(t128, t128_fenced)
+    _close(t128, ref, _tol(t16), "fused GroupNorm + conv3x3, 128-pixel tiles")
+    # the same kernel without a normalisation (policy "small") against the plain convolution of the production dispatch
+    old = ops.CONV_POLICY
+    try:
+        ops.CONV_POLICY = "small"
+        plain_small = ops.conv2d(x0, pw, **kw)
+    finally:
+        ops.CONV_POLICY = old
+    plain = ops.conv2d(x0, pw, **kw)
+    refp = F.conv2d(xc, _rt(w, t16), b, padding=1)
+    if emb is not None:
+        refp = refp + emb.cpu()[:, :Cout, None, None]
+    if res is not None:
+        refp = refp + _rt(res, t16)
+    if case.get("act"):
+        refp = F.silu(refp)
+    _close(plain_small, refp.permute(0, 2, 3, 1), _tol(t16), "small-map kernel without gn_in")
+    assert (plain_small.float() - plain.float()).abs().max().item() <= _tol(t16) * refp.abs().max().item()
