@@ -132,6 +132,7 @@ SIGNATURES = {
     "nlc_conv2d_prologue_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_norm_out_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
     "nlc_conv2d_gn_in_supported": (C.c_int, [C.POINTER(ConvDesc), _i]),
+    "nlc_resblock_small": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _vp, _i, _vp]),
     "nlc_groupnorm_coef": (C.c_int, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "nlc_conv_first": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "nlc_conv_first_stats_partials": (C.c_int, [_i, _i, _i, _i, _i, _i, _i]),

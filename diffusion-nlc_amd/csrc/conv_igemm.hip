@@ -403,7 +403,7 @@ static int check_counters(const KParams& p, hipStream_t stream) {
     return NLC_OK;
 }
 
-extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
+static int validate_conv_desc(const nlc_conv_desc* d, int dtype) {
     NLC_REQUIRE(d != nullptr, "nlc_conv2d: null descriptor");
     NLC_REQUIRE(nlc_dtype_ok(dtype), "nlc_conv2d: bad dtype %d", dtype);
     NLC_REQUIRE(d->math == NLC_MATH_NATIVE || (d->math == NLC_MATH_F16X3 && dtype == NLC_F32), "nlc_conv2d: math %d needs dtype NLC_F32", d->math);
@@ -438,6 +438,55 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     NLC_REQUIRE(!d->gn_coef || d->gn_act == NLC_ACT_NONE || d->gn_act == NLC_ACT_SILU, "nlc_conv2d: bad gn_act %d", d->gn_act);
     NLC_REQUIRE(d->policy >= NLC_CONV_AUTO && d->policy <= NLC_CONV_FORCE_SMALL, "nlc_conv2d: bad policy %d", d->policy);
     NLC_REQUIRE(d->stats_granule == 0 || d->stats_granule == 4 || d->stats_granule == 8, "nlc_conv2d: stats_granule must be 0 (= 8), 4 or 8");
+    return NLC_OK;
+}
+
+// The small-map kernel's parameter block for this descriptor: NLC_OK (sp filled), NLC_EUNSUPPORTED (not a small-map launch), or an error
+static int prepare_small(const nlc_conv_desc* d, const KParams& p, int dtype, hipStream_t stream, SmallParams& sp) {
+    if (!small_wanted(d, p, dtype, sp.geo)) return NLC_EUNSUPPORTED;
+    sp.k = p;
+    if (d->gn_in) { const int gr = fill_gn_in(d->gn_in, p, sp.gn); if (gr != NLC_OK) return gr; }
+    if (d->stats_out) {
+        NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * (p.Cout / p.stats_gran) * 4 * (int64_t)sizeof(long long), "nlc_conv2d: stats_out too small");
+        NLC_REQUIRE((reinterpret_cast<uintptr_t>(d->stats_out) & 15) == 0, "nlc_conv2d: stats_out must be 16-byte aligned (its consumers read 16-byte pairs)");
+        sp.k.stats = (long long*)d->stats_out;
+    }
+    if (sp.geo.ks > 1) {
+        NLC_REQUIRE(d->workspace && d->workspace_bytes >= nlc_conv_small_split_bytes(p, sp.geo),
+                    "nlc_conv2d: this small-map launch splits K %d ways: it needs the workspace of nlc_conv2d_workspace_bytes", sp.geo.ks);
+        sp.k.partial = (float*)d->workspace;
+        if (d->debug & 1) { const int cr = check_counters(sp.k, stream); if (cr != NLC_OK) return cr; }
+    }
+    return NLC_OK;
+}
+
+extern "C" int nlc_resblock_small(const nlc_conv_desc* d1, const nlc_conv_desc* d2, void* barrier, int dtype, void* stream) {
+    int rc = validate_conv_desc(d1, dtype);
+    if (rc != NLC_OK) return rc;
+    rc = validate_conv_desc(d2, dtype);
+    if (rc != NLC_OK) return rc;
+    NLC_REQUIRE(barrier && (reinterpret_cast<uintptr_t>(barrier) & 7) == 0, "nlc_resblock_small: barrier must be two zeroed, 8-byte aligned ints");
+    NLC_REQUIRE(d2->x0 == d1->out && !d2->x1, "nlc_resblock_small: the second convolution's input must be the first one's output");
+    NLC_REQUIRE(d1->workspace == d2->workspace, "nlc_resblock_small: both convolutions use ONE split-K workspace (the phases do not overlap)");
+    KParams p1, p2;
+    fill_params(d1, p1);
+    fill_params(d2, p2);
+    SmallParams s1{}, s2{};
+    rc = prepare_small(d1, p1, dtype, (hipStream_t)stream, s1);
+    if (rc != NLC_OK) { if (rc == NLC_EUNSUPPORTED) nlc_set_error("nlc_resblock_small: the first convolution is not a small-map launch"); return rc; }
+    rc = prepare_small(d2, p2, dtype, (hipStream_t)stream, s2);
+    if (rc != NLC_OK) { if (rc == NLC_EUNSUPPORTED) nlc_set_error("nlc_resblock_small: the second convolution is not a small-map launch"); return rc; }
+    s1.out_sc1 = 1;                                  // h crosses the grid barrier to other CUs: write-through
+    rc = nlc_resblock_small_dispatch(s1, s2, (int*)barrier, dtype, (hipStream_t)stream);
+    if (rc == NLC_EUNSUPPORTED) nlc_set_error("nlc_resblock_small: no one-launch form for this geometry (the two convolutions must tile alike and the grid must be resident at once)");
+    return rc;
+}
+
+extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
+    { const int vr = validate_conv_desc(d, dtype); if (vr != NLC_OK) return vr; }
+    const int per = nlc_is16(dtype) ? 8 : 4;
+    const int kbe = nlc_is16(dtype) ? Mma<bf16_raw>::KBE : Mma<float>::KBE;
+    (void)per; (void)kbe;
 
     if ((d->debug & 2) && d->math == NLC_MATH_F16X3) { const int cr = check_x3_domain(d, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
     KParams p;
@@ -447,22 +496,9 @@ extern "C" int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream) {
     const bool force_generic = d->policy == NLC_CONV_GENERIC;
     {
         SmallParams sp{};
-        if (small_wanted(d, p, dtype, sp.geo)) {
-            sp.k = p;
-            if (d->gn_in) { const int gr = fill_gn_in(d->gn_in, p, sp.gn); if (gr != NLC_OK) return gr; }
-            if (d->stats_out) {
-                NLC_REQUIRE(d->stats_bytes >= (int64_t)p.B * (p.Cout / p.stats_gran) * 4 * (int64_t)sizeof(long long), "nlc_conv2d: stats_out too small");
-                NLC_REQUIRE((reinterpret_cast<uintptr_t>(d->stats_out) & 15) == 0, "nlc_conv2d: stats_out must be 16-byte aligned (its consumers read 16-byte pairs)");
-                sp.k.stats = (long long*)d->stats_out;
-            }
-            if (sp.geo.ks > 1) {
-                NLC_REQUIRE(d->workspace && d->workspace_bytes >= nlc_conv_small_split_bytes(p, sp.geo),
-                            "nlc_conv2d: this small-map launch splits K %d ways: it needs the workspace of nlc_conv2d_workspace_bytes", sp.geo.ks);
-                sp.k.partial = (float*)d->workspace;
-                if (d->debug & 1) { const int cr = check_counters(sp.k, (hipStream_t)stream); if (cr != NLC_OK) return cr; }
-            }
-            return nlc_conv_small_dispatch(sp, dtype, (hipStream_t)stream);
-        }
+        const int pr = prepare_small(d, p, dtype, (hipStream_t)stream, sp);
+        if (pr == NLC_OK) return nlc_conv_small_dispatch(sp, dtype, (hipStream_t)stream);
+        if (pr != NLC_EUNSUPPORTED) return pr;
         NLC_REQUIRE(!d->gn_in, "nlc_conv2d: gn_in given but this launch cannot apply it (ask nlc_conv2d_gn_in_supported first)");
     }
     if (!force_generic) {

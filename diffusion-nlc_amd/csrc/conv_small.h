@@ -37,3 +37,5 @@ struct SmallParams {
 bool nlc_conv_small_geom(const KParams& p, int dtype, SmallGeom& g);
 int64_t nlc_conv_small_split_bytes(const KParams& p, const SmallGeom& g);
 int nlc_conv_small_dispatch(const SmallParams& sp, int dtype, hipStream_t stream);
+// one launch for a ResBlock's two convolutions (sp1's output is sp2's input); bar: two zeroed ints
+int nlc_resblock_small_dispatch(const SmallParams& sp1, const SmallParams& sp2, int* bar, int dtype, hipStream_t stream);

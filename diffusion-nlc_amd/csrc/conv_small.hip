@@ -561,6 +561,49 @@ __global__ __launch_bounds__(WM * 128, WM / 2) void conv_small_kernel(const Smal
     (void)conv_small_body<T, WM, NWST>(sp, smem, blockIdx.x);
 }
 
+// A ResBlock's two convolutions in ONE launch (the A/B of VERDICT r04 item 1; tools/resblock_bench.py): every workgroup runs its
+// share of conv1 (h = conv3x3(act(GN(x))) + bias (+ emb), written write-through, totals of h added), all workgroups meet at a grid
+// barrier, then its share of conv2 (out = conv3x3(act(GN(h) FiLM)) + bias + x).  The grid is resident at once (host-checked: at most
+// one workgroup per CU, >= 96 KB of LDS each).  Hand-off of h and its totals through the barrier: sc1 stores (and memory-side
+// atomics), every wave's vmcnt(0), workgroup barrier, ONE lane's agent-scope add; that lane polls (sc1 loads, bounded), then ONE
+// agent-scope acquire (invalidates this CU's L1; h's lines were never in any L2: sc1 stores drop them), vmcnt(0), workgroup barrier,
+// plain loads - the guide's consumer form.  `bar`: two words (arrive, depart), zero between launches (the last to leave resets them).
+template <typename T, int WM, int NWST>
+__global__ __launch_bounds__(WM * 128, WM / 2) void resblock_small_kernel(const SmallParams sp1, const SmallParams sp2, int* bar) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)conv_small_body<T, WM, NWST>(sp1, smem, blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this lane's stores of h, its statistics atomics and counter resets are done
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = gridDim.x;
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && ++spins < SMALL_SPIN_MAX) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == n - 1) {                                       // everyone has passed the poll: re-zero for the next launch
+            __hip_atomic_store(bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(bar + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    (void)conv_small_body<T, WM, NWST>(sp2, smem, blockIdx.x);
+}
+
+template <typename T, int WM, int NWST>
+int launch_resblock(const SmallParams& sp1, const SmallParams& sp2, int* bar, hipStream_t stream) {
+    static DeviceOnce once;
+    (void)nlc_device_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_small_kernel<T, WM, NWST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const int lds = small_a_bytes(sp1.geo) + NWST * WST_BYTES + sp1.geo.nseg * sp1.geo.nb * 64 * 8;
+    hipLaunchKernelGGL((resblock_small_kernel<T, WM, NWST>), dim3(sp1.geo.MT * sp1.k.NT * sp1.geo.ks), dim3(WM * 128), lds, stream, sp1, sp2, bar);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { nlc_set_error("nlc_resblock_small: launch failed: %s", hipGetErrorString(e)); return NLC_ELAUNCH; }
+    return NLC_OK;
+}
+
 template <typename T, int WM, int NWST>
 int launch_small(const SmallParams& sp, hipStream_t stream) {
     static DeviceOnce once;
@@ -658,5 +701,19 @@ int nlc_conv_small_dispatch(const SmallParams& sp, int dtype, hipStream_t stream
     NLC_SMALL_CASE(2, 3) NLC_SMALL_CASE(2, 4) NLC_SMALL_CASE(2, 6) NLC_SMALL_CASE(2, 8)
     NLC_SMALL_CASE(4, 3) NLC_SMALL_CASE(4, 4) NLC_SMALL_CASE(4, 6) NLC_SMALL_CASE(4, 8)
 #undef NLC_SMALL_CASE
+    return NLC_EUNSUPPORTED;
+}
+
+// Both convolutions of a ResBlock in one launch: same geometry for both (Cin == Cout, no projection), a grid that is resident at once.
+// Instantiated for the geometries of the measured shapes only (tools/resblock_bench.py); anything else: NLC_EUNSUPPORTED.
+int nlc_resblock_small_dispatch(const SmallParams& sp1, const SmallParams& sp2, int* bar, int dtype, hipStream_t stream) {
+    const SmallGeom &a = sp1.geo, &b = sp2.geo;
+    if (a.wm != b.wm || a.nwst != b.nwst || a.nb != b.nb || a.ks != b.ks || a.MT != b.MT || sp1.k.NT != sp2.k.NT || a.slots != b.slots || a.nseg != b.nseg)
+        return NLC_EUNSUPPORTED;
+    const int ncu = g_small_dev.ncu[nlc_device_once(g_small_dev, [] {})];
+    if ((int64_t)a.MT * sp1.k.NT * a.ks > ncu) return NLC_EUNSUPPORTED;
+#define NLC_RB_CASE(WMV, STV) if (a.wm == WMV && a.nwst == STV) { NLC_SWITCH_16(dtype, return (launch_resblock<T16, WMV, STV>(sp1, sp2, bar, stream))); }
+    NLC_RB_CASE(2, 8) NLC_RB_CASE(2, 6) NLC_RB_CASE(4, 3)
+#undef NLC_RB_CASE
     return NLC_EUNSUPPORTED;
 }

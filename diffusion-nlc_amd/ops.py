@@ -262,7 +262,7 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
            act: int = ACT_NONE, out_nchw_f32: bool = False, use_bias: bool = True,
            emit_stats: bool = True, allow_split: bool = False, gn_coef: Optional[torch.Tensor] = None,
            gn_act: int = ACT_NONE, query_prologue: bool = False, res_upsample2x: bool = False,
-           norm_out: bool = False, query_norm_out: bool = False, gn_in=None, query_gn_in: bool = False):
+           norm_out: bool = False, query_norm_out: bool = False, gn_in=None, query_gn_in: bool = False, desc_only: bool = False):
     """Implicit-GEMM conv on [B,H,W,C] (or linear on [M,K] viewed as B=M,H=W=1).
     ``emit_stats``: let the epilogue also write the GroupNorm statistics of the output when the launch supports it
     (bf16 LDS-halo kernel); the following ``groupnorm`` then skips its statistics pass.
@@ -359,6 +359,8 @@ def conv2d(x0: torch.Tensor, pw: PackedConv, *, x1: Optional[torch.Tensor] = Non
         if need > 0:
             ws = _conv_workspace(x0.device, need)
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if desc_only:                                # (resblock_small: the caller launches; everything the descriptor points into is returned too)
+        return d, out, (x0, x1, res, emb, gn_in, pw)
     prof = CONV_PROFILE
     if prof is not None:
         # bench.py's roofline leg: HIP events on the launch stream around this one kernel
@@ -432,6 +434,33 @@ def gn_in_spec(x0: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[t
     spec = _ext.GnIn(stats0=s0.data_ptr(), stats1=_ptr(s1), granule0=g0, granule1=g1, groups=groups, eps=eps, gamma=_ptr(gamma),
                      beta=_ptr(beta), scale=_ptr(scale), shift=_ptr(shift), ss_stride=ss_stride, act=ACT_SILU if silu else ACT_NONE)
     return (spec, s0, s1, gamma, beta, scale, shift)
+
+
+_RB_BARRIER: dict = {}       # device -> two zeroed ints (the one-launch ResBlock's grid barrier; the kernel leaves them zero)
+
+
+def resblock_small(x: torch.Tensor, c1: PackedConv, c2: PackedConv, g1, b1, g2, b2, *, groups: int, eps: float,
+                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+                   emb1: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """EXPERIMENT (tools/resblock_bench.py; not used by the networks): conv2(act(GN2(conv1(act(GN1(x))) (+ emb1)) FiLM)) + x in ONE
+    launch (nlc_resblock_small), or None when there is no one-launch form for this geometry."""
+    lib = _ext.load()
+    spec1 = gn_in_spec(x, g1, b1, groups=groups, eps=eps, silu=True)
+    if spec1 is None or not conv2d(x, c1, query_gn_in=True):
+        return None
+    d1, h, keep1 = conv2d(x, c1, gn_in=spec1, emb=emb1, desc_only=True)
+    spec2 = gn_in_spec(h, g2, b2, groups=groups, eps=eps, silu=True, scale=scale, shift=shift)
+    if spec2 is None or not conv2d(h, c2, query_gn_in=True):
+        return None
+    d2, out, keep2 = conv2d(h, c2, gn_in=spec2, res=x, desc_only=True)
+    bar = _RB_BARRIER.get(x.device)
+    if bar is None:
+        bar = _RB_BARRIER[x.device] = torch.zeros(2, device=x.device, dtype=torch.int32)
+    rc = lib.nlc_resblock_small(C.byref(d1), C.byref(d2), bar.data_ptr(), dtype_enum(x.dtype), _stream())
+    if rc == _ext.NLC_EUNSUPPORTED:
+        return None
+    check(rc, "nlc_resblock_small")
+    return out
 
 
 # networks: on the small maps (8 / 16 / 32 pixels wide) the GroupNorm (+FiLM) + SiLU in front of a ResBlock's 3x3 convolutions is applied

@@ -230,6 +230,15 @@ int nlc_conv2d_norm_out_supported(const nlc_conv_desc* d, int dtype);
  * the kernel that WILL run: set desc->gn_in (or policy NLC_CONV_FORCE_SMALL) before asking them. */
 int nlc_conv2d_gn_in_supported(const nlc_conv_desc* d, int dtype);
 
+/* EXPERIMENT, measured and not used by the networks ("One launch per ResBlock"): both 3x3 convolutions of a ResBlock
+ * whose input and output widths are equal (/root/reference/src/unet_adm.py:236-256 without a skip projection) in ONE launch of the
+ * small-map kernel - conv1 (d1, with d1->gn_in = in_layers' GroupNorm + SiLU), a grid-wide barrier, conv2 (d2, with d2->gn_in =
+ * out_layers' GroupNorm (+FiLM) + SiLU described by d1->stats_out, d2->x0 = d1->out, d2->res = the block input).  Both descriptors
+ * must be small-map launches that tile alike (nlc_conv2d_gn_in_supported), share ONE workspace, and their grid must be resident
+ * at once (at most one workgroup per CU) - else NLC_EUNSUPPORTED and nothing is launched.  barrier: two ints, zero between launches
+ * (the kernel leaves them zero).  Results are those of nlc_conv2d(d1) followed by nlc_conv2d(d2), bit for bit. */
+int nlc_resblock_small(const nlc_conv_desc* d1, const nlc_conv_desc* d2, void* barrier, int dtype, void* stream);
+
 /* First-layer convolution for tiny Cin (<=4): reads the sampler state in the reference's
  * own layout (NCHW f32), applies the per-sample input scale c_in[b] (convert_coordinate,
  * src/experiments.py:273-282; c_in of :782,796), and writes NHWC compute dtype.

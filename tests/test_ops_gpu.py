@@ -1423,3 +1423,31 @@ def test_small_map_conv_applies_the_groupnorm_of_its_input(case, t16):
         refp = F.silu(refp)
     _close(plain_small, refp.permute(0, 2, 3, 1), _tol(t16), "small-map kernel without gn_in")
     assert (plain_small.float() - plain.float()).abs().max().item() <= _tol(t16) * refp.abs().max().item()
+
+
+@pytest.mark.parametrize("t16", T16, ids=T16_IDS)
+@pytest.mark.parametrize("shape", [(4, 8, 8, 128), (2, 16, 16, 256), (8, 8, 8, 512)], ids=lambda s: "x".join(map(str, s)))
+def test_one_launch_resblock_equals_its_two_fused_launches(shape, t16):
+    """nlc_resblock_small (an experiment, not used by the networks): conv1, a grid barrier and conv2 in one launch - the bits of
+    nlc_conv2d(gn_in) twice; repeated launches agree (the barrier words and the arrival counters are left zero)."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(_seed(shape))
+    B, H, W, Cc = shape
+    z = torch.randn(B, 64, H, W, generator=g)
+    x = ops.conv2d(_nhwc(z, t16), ops.pack_conv(torch.randn(Cc, 64, 1, 1, generator=g) / 8, torch.randn(Cc, generator=g) * 0.3, t16, _dev()))
+    c1 = ops.pack_conv(torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc), torch.randn(Cc, generator=g) * 0.1, t16, _dev())
+    c2 = ops.pack_conv(torch.randn(Cc, Cc, 3, 3, generator=g) / math.sqrt(9 * Cc), torch.randn(Cc, generator=g) * 0.1, t16, _dev())
+    g1, b1, g2, b2 = [(torch.rand(Cc, generator=g) + 0.5).to(_dev()) if i % 2 == 0 else (torch.randn(Cc, generator=g) * 0.2).to(_dev()) for i in range(4)]
+    ss = (torch.randn(B, 2 * Cc, generator=g) * 0.3).to(_dev())
+    sc, sh = ss[:, :Cc], ss[:, Cc:]
+    h = ops.conv2d(x, c1, gn_in=ops.gn_in_spec(x, g1, b1, groups=32, eps=1e-5, silu=True))
+    want = ops.conv2d(h, c2, gn_in=ops.gn_in_spec(h, g2, b2, groups=32, eps=1e-5, silu=True, scale=sc, shift=sh), res=x)
+    got = ops.resblock_small(x, c1, c2, g1, b1, g2, b2, groups=32, eps=1e-5, scale=sc, shift=sh)
+    assert got is not None
+    for _ in range(3):
+        again = ops.resblock_small(x, c1, c2, g1, b1, g2, b2, groups=32, eps=1e-5, scale=sc, shift=sh)
+        assert torch.equal(again, got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(ops.ride_stats(got), ops.ride_stats(want))
+    assert int(ops._RB_BARRIER[x.device].abs().sum()) == 0
