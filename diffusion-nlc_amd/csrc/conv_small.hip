@@ -634,13 +634,13 @@ bool small_geom_for(const KParams& p, int wm, int ncu, SmallGeom& g) {
     if (g.slots > 7 * (wm * 16)) return false;
     if (g.MT * p.NT > 511) return false;                      // arrival + departure counters: 2 x 512 words (the last one: the give-up mark)
     const int ncb = p.Ctot / 64;
-    // k-slice: NB in {4, 2, 1} blocks of 64 channels (whole slices, at most 8 of them; the weight ring needs >= 3 stages beside the
+    // k-slice: NB in {4, 3, 2, 1} blocks of 64 channels (whole slices, at most 8 of them; the weight ring needs >= 3 stages beside the
     // input slice).  ONE round of workgroups (measured: a second round costs more than the fused normalisation saves): the NB that
     // puts the most workgroups on the chip without exceeding one per CU, the larger NB (fewer partial sums) on a tie
     int nb = 0;
     int64_t best = 0;
     const int forced = (p.tuning >> 24) & 3;                  // tuning bits 24-25: NB = 1 / 2 / 4 (A/B)
-    for (int c = 4; c >= 1; c >>= 1) {
+    for (int c = 4; c >= 1; --c) {                            // (3: the 384- / 768- / 1536-channel concatenations of the up paths)
         if (ncb % c || ncb / c > 8) continue;
         if (c * g.slots * KB_BYTES + 3 * WST_BYTES + nseg * c * 64 * 8 > 160 * 1024) continue;
         if (forced && c != (forced == 3 ? 4 : forced)) continue;

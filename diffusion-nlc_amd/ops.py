@@ -471,7 +471,7 @@ FUSE_GN_SMALL = True
 def config_key() -> tuple:
     """Every module-level switch that changes which kernels / layouts a network evaluation launches.  HipModule keys its captured
     hipGraphs by it (a graph bakes the configuration it was captured under); setters of these switches need no other hook."""
-    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_POOL, FUSE_GN_SKIP, FUSE_GN_SMALL, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2,
+    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_CONV_NT1, FUSE_GN_POOL, FUSE_GN_SKIP, FUSE_GN_SMALL, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2,
             WS_GENERATION)
 
 
@@ -627,6 +627,10 @@ def groupnorm_pool2x2_supported(x: torch.Tensor) -> bool:
 # 8.4 ms - every (16x16 patch x 128 cout) tile normalises its own halo, i.e. each input element NT x 1.27 = 2.5 ... 5 times, on
 # the same SIMD issue ports the MFMAs need: 5.89 vs 6.16 images/s (profiles/r02_summary.md).  Kept, tested, one switch away.
 FUSE_GN_CONV = False
+# ... except where the convolution has ONE channel tile (Cout <= 128: the two highest-resolution levels of the CelebA-HQ UNet): every
+# input element is then normalised 1.27 times (the halo overlap) instead of 2.5-5 times, and the prologue beats the separate pass
+# (measured: profiles/r05_summary.md)
+FUSE_GN_CONV_NT1 = True
 FUSE_GN_SKIP = True          # Norm.with_skip: a ResBlock's skip projection also writes act(GroupNorm(x)) of its input (nlc_conv_desc.norm_out)
 
 

@@ -1318,6 +1318,7 @@ SMALL_CASES = [
     dict(B=1, C0=128, C1=256, H=32, W=32, Cout=128, groups=8, film=True),                 # concatenated input, 48-channel groups straddling the sources
     dict(B=2, C0=256, C1=128, H=8, W=16, Cout=128, groups=8, res=True, act=True),         # non-square map, 8 rows x 16
     dict(B=16, C0=512, H=8, W=8, Cout=1024, groups=32, film=True, res=False),             # two blocks per slice (256 workgroups)
+    dict(B=8, C0=512, C1=256, H=16, W=16, Cout=512, groups=32, res=True),                 # three blocks per slice: 768 -> 512 (cfg 4's up path)
     dict(B=16, C0=1024, H=8, W=8, Cout=1024, groups=32, film=True, res=True),             # four blocks per slice: ADM-256's 8x8 level
 ]
 
