@@ -323,10 +323,11 @@ template <int TP> __device__ __forceinline__ void dma_wait_tiles(int tiles) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// Softmax bookkeeping, built around what bounds this kernel: at 64 channels per head a 64-key tile is 16 MFMAs (512 matrix cycles per
-// wave) against one v_exp_f32 per score (8 issue cycles each) plus whatever else runs per score, so every per-score VALU instruction
-// besides the exponential costs matrix utilisation (round 2: 11.4 VALU per MFMA, matrix pipe 28 % busy).  Per score there is now
-// the exponential and half a convert, nothing else:
+// Softmax bookkeeping.  Per wave and 64-key tile at 64 channels per head: 20 MFMAs (8 S^T + 8 O^T + 4 row sums) = 640 matrix cycles
+// against ~95 VALU instructions - 32 v_exp_f32 at 8 issue cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"), 16 v_max3,
+// 16 v_cvt_pk and ~30 others at 4 - = ~500 issue cycles: neither port is saturated, and every per-score VALU instruction that was
+// removed bought a few per cent at most (round 2: 11.4 VALU per MFMA, matrix pipe 28 % busy).  Per score there is now the exponential
+// and half a convert, nothing else:
 //   * BASE2 (log2 e folded into the q projection at pack time, nlc_attention(logit_log2 = 1)): p = 2^s needs no multiply;
 //   * no per-tile maximum subtraction: softmax is invariant to the offset, and 2^s cannot overflow while the running maximum stays
 //     below 2^64 (bf16 probabilities have f32's exponent range; for f16 the window is 2^+-8), so the offset `moff` stays 0
@@ -336,15 +337,23 @@ template <int TP> __device__ __forceinline__ void dma_wait_tiles(int tiles) {
 //   * the row sums l come from the matrix pipe: one more MFMA per k-step with an all-ones A operand and the same P^T fragment
 //     (every row of the result is sum_k P[k][q]; only register 0 is kept consistent), instead of 32 adds per tile - and they sum
 //     the ROUNDED probabilities the PV product uses.
+// Where a launch's time goes (round 5, in-kernel stamps: tools/attn_stamps.py, profiles/r05j_attn_stamps.log; 8 heads, T = 1024, B = 16:
+// 512 workgroups = two per CU, all resident from the start): a wave lives 67-69 k cycles at an in-kernel clock of 1.80-1.84 GHz
+// (s_memtime / s_memrealtime) - prologue 7 k, sixteen tiles of 2.9 k (S^T + tile maximum 1.37 k, exponentials 0.35 k, converts + O^T
+// 0.63 k, DMA wait + barrier 0.55 k - the older half of the workgroup waits 0.8 k there for the younger half, the arbitration loser
+// on every segment), stores 4.8 k.  Four waves per SIMD x 640 matrix cycles per tile = 2 560 of every 2 930: the tile loop keeps the
+// matrix pipe ~87 % busy; over a median wave's lifetime that is 60 %, and over the whole launch 48-50 % - the two workgroups of a CU
+// do not finish together (wave lifetimes 30 ... 45 us: the first-dispatched one wins the arbitration throughout, and the last third
+// of the launch runs with one workgroup per CU).  (The 37-38 % of rounds 3-4 divided the same matrix cycles by a cycle count derived
+// from GRBM_GUI_ACTIVE, which reads high on launches this short - the guide's DVFS note - not by the in-kernel clock.)  Tried on top
+// (round 5, interleaved A/B, profiles/r05j_attn_prio.log): static priority for the second-dispatched workgroup, priority alternating
+// between the two every 1 / 2 / 4 tiles - level or slower.
 // QB = 32-query blocks per wave.  QB = 2 (round 4; instantiate <T, BASE2, 4, NST, 2> to measure): a wave owns 64 queries; every K
 // fragment read feeds the S^T MFMAs of both blocks and every V^T fragment read the O^T MFMAs of both - half the LDS fragment reads per
 // MFMA - and the two blocks are independent dependency chains inside one wave.  ~2x the registers (230 VGPRs: two waves per SIMD
 // instead of four), so W = 4 waves per workgroup keeps 256 queries per workgroup.  Measured level with QB = 1 (profiles/r04_summary.md:
 // 48.3 vs 47.6 us under the counters at T = 1024, 12.9 vs 12.2 us at T = 256; LDS instructions halved, time a wave waits for LDS
-// 2.07 M -> 0.44 M cycles, waves parked 36 % -> 24 %, matrix pipe 36.6 % vs 37.8 % busy): neither the fragment reads nor the lockstep
-// of the phases bound this kernel.  What does: one v_exp_f32 per score is a quarter-rate (16-cycle) instruction - 32 per lane and tile
-// = 512 issue cycles per wave against 640 matrix cycles, ~30 % of all SIMD cycles on top of the 38 % the MFMAs take - and the two
-// only overlap across waves.  QB = 1 ships.
+// 2.07 M -> 0.44 M cycles): neither the fragment reads nor the lockstep of the phases bound this kernel.  QB = 1 ships.
 template <typename T, bool BASE2, int W, int NST, int QB = 1>
 __global__ __launch_bounds__(W * 64, QB == 2 ? 2 : (W == 8 ? 2 : 4)) void attn_d64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int H) {
     constexpr int F_NST = NST;
@@ -370,15 +379,6 @@ __global__ __launch_bounds__(W * 64, QB == 2 ? 2 : (W == 8 ? 2 : 4)) void attn_d
     const T* qb = qkv + (int64_t)b * Tn * tok + (int64_t)hd * 64;
     const T* kb = qb + (int64_t)H * 64;
     const T* vb = qb + (int64_t)2 * H * 64;
-
-    // Q^T fragments (B operand): lane (q, h) holds Q[q0 + q][16 s + 8 h + j], j = 0..7
-    uint4 qf[QB][4];
-#pragma unroll
-    for (int u = 0; u < QB; ++u) {
-        const T* qp = qb + (int64_t)(q0 + 32 * u + q) * tok + h * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const uint4*>(qp + s * 16);
-    }
 
     // this wave's DMA piece of every tile: rows 8 wave .. 8 wave + 7; lane -> (row, 16-byte slot), source chunk = slot ^ swizzle(row)
     const int drow = wave * 8 + (lane >> 3), dslot = lane & 7;
@@ -428,14 +428,25 @@ __global__ __launch_bounds__(W * 64, QB == 2 ? 2 : (W == 8 ? 2 : 4)) void attn_d
     const uint4 ones = make_uint4(one2, one2, one2, one2);
 
     const int ntiles = Tn / (FKV * F_SUB);               // >= 4 (dispatch: T % 256 == 0)
-    // the compiler's own bookkeeping must see the Q loads as complete BEFORE the first DMA: otherwise it waits for them with counted
-    // vmcnt(N) inside the loop, and since it cannot see the asm DMAs those counts drain the prefetch at once
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
     constexpr int DEPTH = F_NST - 1;                     // tiles in flight beyond the one being computed
     constexpr int TP = 2 * PP;                           // DMA pieces per wave and tile (K and V)
+    // The first K / V tiles go out BEFORE the Q loads: one memory round trip for both instead of two in a row (tools/attn_stamps.py:
+    // the prologue was 7.3 k of a wave's 69 k cycles at T = 1024, 3.9 k of 19 k at T = 256).
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) issue(d, d);
-    dma_wait_tiles<TP>(DEPTH - 1);                       // tile 0 landed, the others may fly
+    // Q^T fragments (B operand): lane (q, h) holds Q[q0 + q][16 s + 8 h + j], j = 0..7
+    uint4 qf[QB][4];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        const T* qp = qb + (int64_t)(q0 + 32 * u + q) * tok + h * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const uint4*>(qp + s * 16);
+    }
+    // The compiler's own bookkeeping must see the Q loads as complete BEFORE the loop: otherwise it waits for them with counted
+    // vmcnt(N) inside it, and since it cannot see the asm DMAs those counts drain the prefetch at once.  vmcnt retires in order, so
+    // this wait also covers the DMA issued above (all of it: the first tile is needed now anyway; with deeper rings the later tiles
+    // land a little earlier than they must).
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int st = t & (F_NST - 1);
