@@ -82,8 +82,10 @@ def main():
         "dominant": {"kernel": "conv_halo_kernel<bf16>, 256->256 3x3 @256^2, B=16 (31 % of the conv FLOPs)",
                      "read_bytes_per_launch": d_read, "write_bytes_per_launch": d_write,
                      "traffic_bytes_per_launch": d_read + d_write, "algorithmic_bytes_per_launch": algo},
-        "per_kernel": [{"kernel": k, "launches": v[0], "read_GB": v[1] / 1e9, "write_GB": v[2] / 1e9}
-                       for k, v in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))],
+        # PER NLC STEP (the traces cover `nlc_steps` of them: earlier rounds' files listed the trace totals here and were read as
+        # per-step figures)
+        "per_kernel_per_nlc_step": [{"kernel": k, "launches": v[0] / nsteps, "read_GB": v[1] / 1e9 / nsteps, "write_GB": v[2] / 1e9 / nsteps}
+                                    for k, v in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))],
     }
     print(json.dumps(out, indent=1))
 
