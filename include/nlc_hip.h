@@ -211,6 +211,11 @@ typedef struct nlc_conv_desc {
                          /* LDS (see nlc_gn_in).  Only launches for which nlc_conv2d_gn_in_supported(desc, dtype) returns 1: 16-bit 3x3 /    */
                          /* stride 1 / pad 1 on 8-, 16- or 32-pixel-wide maps, whole 128-pixel x 128-channel tiles, C0 and C0+C1 multiples */
                          /* of 64.  Split-K needs the workspace of nlc_conv2d_workspace_bytes (same layout as for the other kernels).   */
+                         /* With 2 / 4 / 8 splits the tile's workgroups WAIT for each other (distributed reduction): the launch has at   */
+                         /* most one workgroup per CU and expects to be resident at once - true on a stream of its own kernels; a caller */
+                         /* that runs other long-lived kernels CONCURRENTLY on other streams sets tuning bit 23 (the last arriver then   */
+                         /* reduces alone, nobody waits; same bits).  The wait is bounded (~0.2 s) and leaves a non-zero mark in the     */
+                         /* workspace's counter word 1023 when it gives up (reported by debug bit 0).                                   */
 } nlc_conv_desc;
 
 int nlc_conv2d(const nlc_conv_desc* d, int dtype, void* stream);
