@@ -644,7 +644,7 @@ def roofline_leg(wl, x, dtype, args, ms_per_step):
     ach = tot_fl / (tot_ms * 1e-3) / 1e12
     peak = PEAKS[args.dtype]
     out = {"bound": "mfma",
-           "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3, >= 64 tiles) + conv_fast_kernel<{args.dtype},9|1> + conv_pw(r)_kernel<{args.dtype}> (1x1, >= 768 tiles) + conv_igemm_kernel",
+           "kernel": f"nlc_conv2d: conv_halo_kernel<{args.dtype}> (3x3, >= 64 tiles) + conv_small_kernel (3x3 on <= 32-wide maps, GroupNorm fused) + conv_fast_kernel<{args.dtype},9|1> + conv_pw(r)_kernel<{args.dtype}> (1x1, >= 768 tiles) + conv_igemm_kernel",
            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": n,
            "avg_launch_us": 1e3 * tot_ms / max(n, 1), "avg_launch_gflop": tot_fl / max(n, 1) / 1e9,
            # conv time of the instrumented step over the TIMED region's ms_per_step (reproducible from this line:

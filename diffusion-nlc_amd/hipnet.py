@@ -345,7 +345,7 @@ class Norm:
             spec = ops.gn_in_spec(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, silu=silu, x1=x1, scale=scale, shift=shift)
             if spec is not None:
                 return ops.conv2d(x, pw, x1=x1, gn_in=spec, **conv_kw)
-        if (ops.FUSE_GN_CONV or (ops.FUSE_GN_CONV_NT1 and pw.Cout <= 128)) and ops.conv2d(x, pw, x1=x1, query_prologue=True, **{k: v for k, v in conv_kw.items() if k in ("stride", "pad", "out_hw", "upsample2x", "out_nchw_f32")}):
+        if (ops.FUSE_GN_CONV or (ops.FUSE_GN_CONV_NT1 and pw.Cout <= ops.FUSE_GN_CONV_MAXC)) and ops.conv2d(x, pw, x1=x1, query_prologue=True, **{k: v for k, v in conv_kw.items() if k in ("stride", "pad", "out_hw", "upsample2x", "out_nchw_f32")}):
             coef = ops.groupnorm_coef(x, self.gamma, self.beta, groups=self.groups, eps=self.eps, x1=x1, scale=scale, shift=shift)
             if coef is not None:
                 return ops.conv2d(x, pw, x1=x1, gn_coef=coef, gn_act=ACT_SILU if silu else ACT_NONE, **conv_kw)

@@ -471,7 +471,7 @@ FUSE_GN_SMALL = True
 def config_key() -> tuple:
     """Every module-level switch that changes which kernels / layouts a network evaluation launches.  HipModule keys its captured
     hipGraphs by it (a graph bakes the configuration it was captured under); setters of these switches need no other hook."""
-    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_CONV_NT1, FUSE_GN_POOL, FUSE_GN_SKIP, FUSE_GN_SMALL, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2,
+    return (CONV_POLICY, CONV_TUNING, CONV_DEBUG, FUSE_GN_CONV, FUSE_GN_CONV_NT1, FUSE_GN_CONV_MAXC, FUSE_GN_POOL, FUSE_GN_SKIP, FUSE_GN_SMALL, FUSED_GN_STATS, STATS_GRANULE_4, ATTN_BASE2,
             WS_GENERATION)
 
 
@@ -631,6 +631,7 @@ FUSE_GN_CONV = False
 # input element is then normalised 1.27 times (the halo overlap) instead of 2.5-5 times, and the prologue beats the separate pass
 # (measured: profiles/r05_summary.md)
 FUSE_GN_CONV_NT1 = True
+FUSE_GN_CONV_MAXC = 128      # ... i.e. Cout <= this (A/B: 256 = two channel tiles)
 FUSE_GN_SKIP = True          # Norm.with_skip: a ResBlock's skip projection also writes act(GroupNorm(x)) of its input (nlc_conv_desc.norm_out)
 
 
