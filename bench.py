@@ -630,6 +630,7 @@ def roofline_leg(wl, x, dtype, args, ms_per_step):
     graphs = getattr(wl.exp, "use_graphs", False)
     wl.exp.use_graphs = False                       # events cannot be recorded per kernel inside a graph replay
     ops.CONV_PROFILE = prof
+    aprof = ops.ATTN_PROFILE = []
     try:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -638,6 +639,7 @@ def roofline_leg(wl, x, dtype, args, ms_per_step):
         wall = time.perf_counter() - t0
     finally:
         ops.CONV_PROFILE = None
+        ops.ATTN_PROFILE = None
         wl.exp.use_graphs = graphs
     sel = [(e0.elapsed_time(e1), f, shp) for e0, e1, f, d, shp in prof if d == dtype]
     tot_ms, tot_fl, n = sum(m for m, _, _ in sel), sum(f for _, f, _ in sel), len(sel)
@@ -653,6 +655,17 @@ def roofline_leg(wl, x, dtype, args, ms_per_step):
            "measured": "HIP events around every conv launch of one extra (untimed) step",
            "note": "the 1x1 skip projections of the ResBlocks also write act(GroupNorm(x)) of their input (nlc_conv_desc.norm_out): "
                    "their whole launch time counts here, the GroupNorm pass it replaces never did"}
+    if aprof:
+        # the attention launches of the same step (algorithmic QK^T + PV FLOPs; the matrix-pipe utilisation itself is a counter /
+        # in-kernel-clock measurement: profiles/r05_summary.md section 3)
+        ams = sum(e0.elapsed_time(e1) for e0, e1, _, _ in aprof)
+        afl = sum(f for _, _, f, _ in aprof)
+        big = [(e0.elapsed_time(e1), f) for e0, e1, f, shp in aprof if shp[0] >= 1024]
+        out["attention"] = {"launches": len(aprof), "total_ms": ams, "tflops": afl / ams / 1e9, "frac_of_peak": afl / ams / 1e9 / peak,
+                            "share_of_step": ams / ms_per_step}
+        if big:
+            out["attention"]["t1024_launch_us"] = 1e3 * sum(m for m, _ in big) / len(big)
+            out["attention"]["t1024_tflops"] = sum(f for _, f in big) / sum(m for m, _ in big) / 1e9
     dom = []
     if wl.name == "adm256" and wl.res == 256:
         # the dominant launch's OWN fraction of peak (conv3x3 256->256 @256x256: the largest single share of the step)

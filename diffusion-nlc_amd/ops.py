@@ -681,6 +681,9 @@ def attention_logit_scale(spec) -> tuple:
 ATTN_BASE2 = True            # A/B switch of attention_logit_scale (takes effect when a model is (re)packed)
 
 
+ATTN_PROFILE = None          # bench.py's roofline leg: a list that receives (start_event, end_event, QK^T + PV FLOPs) per nlc_attention launch
+
+
 def attention(qkv: torch.Tensor, heads: int, base2: bool = False) -> torch.Tensor:
     """qkv: [B,T,3*H*D] laid out [3][H][D]; returns [B,T,H*D].  ``base2``: the logits are in log2 units (attention_logit_scale)."""
     lib = _ext.load()
@@ -688,8 +691,15 @@ def attention(qkv: torch.Tensor, heads: int, base2: bool = False) -> torch.Tenso
     B, T, C3 = qkv.shape
     D = C3 // (3 * heads)
     out = torch.empty(B, T, heads * D, device=qkv.device, dtype=qkv.dtype)
+    prof = ATTN_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.nlc_attention(qkv.data_ptr(), out.data_ptr(), B, T, heads, D, dtype_enum(qkv.dtype), 1 if base2 else 0, _stream()),
           "nlc_attention")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 4.0 * B * heads * T * T * D, (T, heads, D)))
     return out
 
 

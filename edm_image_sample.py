@@ -11,9 +11,9 @@ sigma_max=start_sigma, sigma_data), fid_helper, set_norm_maxmin, evaluate_edm(sa
 Extensions (not reference flags; all default to the reference's behaviour): ``--synthetic`` replaces the two file lookups and
 the checkpoints by a built-in configuration with deterministic filler weights (the reference ships neither); ``--dtype`` picks
 the HIP-path precision; ``--rho / --S_churn / --S_min / --S_max / --S_noise`` expose EDMImageExperiment's constructor arguments
-that the reference leaves at their defaults; ``--save_png 0`` skips the PNG writes.  With real files ``--load_eps`` must be a
-plain ``state_dict`` (.pt): unpickling NVIDIA's ``persistence`` classes needs the vendored ``dnnlib/torch_utils`` tree, out of
-scope (INTEGRATION.md has the one-line converter).
+that the reference leaves at their defaults; ``--save_png 0`` skips the PNG writes.  With real files ``--load_eps`` is a plain
+``state_dict`` (.pt) or NVIDIA's network pickle (.pkl, as upstream): the latter is read by ``diffusion_nlc_amd.edm_pickle`` without
+the vendored ``dnnlib / torch_utils`` tree and without executing the source text the pickle embeds.
 """
 from __future__ import annotations
 
@@ -140,8 +140,10 @@ def get_args(argv=None):
 
 def _load_state(path):
     if str(path).endswith(".pkl"):
-        raise NotImplementedError(f"{path}: NVIDIA EDM network pickles need the vendored dnnlib / torch_utils tree (out of scope); "
-                                  "convert once to a plain state_dict (INTEGRATION.md, 'NVIDIA EDM pickles') and pass the .pt")
+        # NVIDIA's network pickle (edm_image_sample.py:152-156 upstream: pickle.load(f)['ema'], then .model.state_dict()), read without
+        # dnnlib / torch_utils and without executing the module source it embeds (diffusion_nlc_amd/edm_pickle.py)
+        from diffusion_nlc_amd.edm_pickle import load_edm_pickle
+        return load_edm_pickle(path)
     return torch.load(path, map_location="cpu")
 
 

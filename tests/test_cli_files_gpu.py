@@ -121,5 +121,13 @@ def test_edm_image_sample_from_files_equals_the_synthetic_run(tmp_path, monkeypa
     log, b_samples = edm_image_sample.main(b_args, b_cfg, return_samples=True)
     assert set(log) == {"fid"} and os.path.exists(tmp_path / "files" / "0" / "results.json")
     assert b_samples.shape == (4, 3, 32, 32) and torch.equal(a_samples.cpu(), b_samples.cpu())
-    with pytest.raises(NotImplementedError):
-        edm_image_sample._load_state("store/models/edm-cifar10-32x32-uncond-vp.pkl")     # NVIDIA pickles: documented converter
+    # ... and through an NVIDIA-format network pickle (edm_image_sample.py:152-156 upstream: pickle.load(f)['ema'], .model.state_dict())
+    from tests.test_host_cpu import write_nvidia_format_pickle
+    write_nvidia_format_pickle(tmp_path / "store" / "models" / "edm_tiny.pkl", fill_state_dict(tmpl, seed=0))
+    with open(run / "args.json", "w") as f:
+        json.dump(dict(load_eps="store/models/edm_tiny.pkl", fid_target=None, sigma_block=2, sigma_dropout=0.0, use_sigma_fp16=False,
+                       feat_layer=1), f)
+    c_args, c_cfg = edm_image_sample.get_args(["--config", "cifar10", "--load_sigma", "results/cifar10/6/ema_sigma_ckpt_100.pt",
+                                               "--save_folder", str(tmp_path / "pkl"), *common])
+    _, c_samples = edm_image_sample.main(c_args, c_cfg, return_samples=True)
+    assert torch.equal(a_samples.cpu(), c_samples.cpu())

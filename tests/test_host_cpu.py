@@ -219,3 +219,101 @@ def test_product_schedule_tables_match_reference():
         assert torch.equal(torch.as_tensor(a.min_var_coef), torch.as_tensor(b.min_var_coef)), (style, kw)
     with pytest.raises(ValueError):
         get_sampler("ddim", 1000, 12, sigma_style="Cosine", start_sigma=80, end_sigma=0.02)
+
+
+# ---- NVIDIA EDM network pickles (torch_utils.persistence format) ------------------------------------------------------------------
+def write_nvidia_format_pickle(path, state_dict):
+    """A pickle in the FORMAT of NVIDIA's EDM checkpoints (/root/reference/torch_utils/persistence.py:123-131,185-208): every module
+    is reduced to ``torch_utils.persistence._reconstruct_persistent_obj(dict(type='class', version=6, module_src=..., class_name=...,
+    state=<the module's __dict__>))``.  Built from a state_dict: a tree of stand-in modules (EDMPrecond.model = the network; the
+    network's ``enc`` / ``dec`` are real ``torch.nn.ModuleDict``s as upstream) whose leaves hold the tensors as parameters - or, for
+    ``resample_filter``, as buffers.  ``module_src`` is a dummy string: nothing of the reference's source is written."""
+    import pickle
+    import sys
+    import types
+    import torch
+
+    fake = types.ModuleType("torch_utils.persistence")
+
+    def _reconstruct_persistent_obj(meta):                       # never called here: pickle stores it by qualified name
+        raise RuntimeError("the stock hook would execute module_src")
+    _reconstruct_persistent_obj.__module__ = "torch_utils.persistence"
+    _reconstruct_persistent_obj.__qualname__ = "_reconstruct_persistent_obj"
+    fake._reconstruct_persistent_obj = _reconstruct_persistent_obj
+    pkg = types.ModuleType("torch_utils")
+    pkg.persistence = fake
+
+    class Node(torch.nn.Module):
+        def __reduce__(self):
+            meta = dict(type="class", version=6, module_src="# (source text elided)", class_name=type(self).__name__, state=dict(self.__dict__))
+            return (_reconstruct_persistent_obj, (meta,), None)
+
+    def build(prefix_items):
+        node = Node()
+        children = {}
+        for key, t in prefix_items:
+            head, _, rest = key.partition(".")
+            if not rest:
+                if key.endswith("resample_filter"):
+                    node.register_buffer(key, t.clone())
+                else:
+                    node.register_parameter(key, torch.nn.Parameter(t.clone(), requires_grad=False))
+            else:
+                children.setdefault(head, []).append((rest, t))
+        for head, items in children.items():
+            if head in ("enc", "dec"):                          # upstream: torch.nn.ModuleDict of persistent blocks
+                md = torch.nn.ModuleDict()
+                blocks = {}
+                for rest, t in items:
+                    bname, _, brest = rest.partition(".")
+                    blocks.setdefault(bname, []).append((brest, t))
+                for bname, bitems in blocks.items():
+                    md[bname] = build(bitems)
+                node.add_module(head, md)
+            else:
+                node.add_module(head, build(items))
+        return node
+
+    precond = Node()
+    precond.add_module("model", build(list(state_dict.items())))
+    precond.sigma_data = 0.5
+    old = {k: sys.modules.get(k) for k in ("torch_utils", "torch_utils.persistence")}
+    sys.modules["torch_utils"], sys.modules["torch_utils.persistence"] = pkg, fake
+    try:
+        with open(path, "wb") as f:
+            pickle.dump(dict(ema=precond, loss_fn=None, augment_pipe=None, dataset_kwargs=dict(resolution=32)), f)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_edm_pickle_reader_needs_no_dnnlib_and_executes_nothing(tmp_path):
+    """diffusion_nlc_amd.edm_pickle: the state_dict of an NVIDIA-format network pickle, read with torch_utils / dnnlib absent, equals the
+    tensors that went in, under the reference's key names; a pickle that references any other global is refused."""
+    import pickle
+    import sys
+    import torch
+    from diffusion_nlc_amd.edm_pickle import load_edm_pickle
+    from diffusion_nlc_amd.filler import fill_state_dict
+    from tests.util import load_specs, template_from_spec
+    sd = fill_state_dict(template_from_spec(load_specs()["edm_tiny"]["eps"]), seed=3)
+    write_nvidia_format_pickle(tmp_path / "net.pkl", sd)
+    assert "torch_utils" not in sys.modules and "dnnlib" not in sys.modules
+    got = load_edm_pickle(tmp_path / "net.pkl")
+    assert list(got) == list(sd) or set(got) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(got[k], v), k
+    # a pickle whose reduce would RUN something foreign (here: create a file) loads as inert stand-ins - nothing runs
+    import subprocess
+
+    class Evil:
+        def __reduce__(self):
+            return (subprocess.check_call, (["touch", str(tmp_path / "pwned")],))
+    evil = tmp_path / "evil.pkl"
+    with open(evil, "wb") as f:
+        pickle.dump(dict(ema=Evil()), f)
+    assert load_edm_pickle(evil, submodule="") == {}
+    assert not (tmp_path / "pwned").exists()
