@@ -682,9 +682,10 @@ bool nlc_conv_small_geom(const KParams& p, int dtype, SmallGeom& g) {
     auto can_dist = [&](const SmallGeom& q) { return (q.ks == 2 || q.ks == 4 || q.ks == 8) && (int64_t)q.MT * p.NT * q.ks <= ncu; };
     // 256-pixel tiles (half the weight bytes per MFMA, twice the partial sums at equal LDS): only with the distributed reduction (or
     // no split; their register budget has no room for the last arriver's read-back), and - measured, tools/resblock_bench.py - only
-    // where the 128-pixel form is left with a three-stage weight ring (four-block slices) and they still fill >= 3/4 of the chip
+    // where the 128-pixel form is left with a three-stage weight ring (four-block slices) AND splits K itself (unsplit it has no partial
+    // sums at all: 256 ch @8x8, B = 200: 70.6 vs 74.9 us per ResBlock) and they still fill >= 3/4 of the chip
     ok4 = ok4 && (g4.ks == 1 || can_dist(g4));
-    const bool use4 = ok4 && (!ok2 || (g2.nwst < 4 && (int64_t)g4.MT * p.NT * g4.ks * 4 >= ncu * 3));
+    const bool use4 = ok4 && (!ok2 || (g2.nwst < 4 && g2.ks > 1 && (int64_t)g4.MT * p.NT * g4.ks * 4 >= ncu * 3));
     if (!use4 && !ok2) return false;
     g = use4 ? g4 : g2;
     g.dist = g.ks > 1 && can_dist(g) && (g.wm == 4 || !(p.tuning & (1 << 23)));                           // tuning bit 23: last-arriver form (A/B; 128-pixel tiles)
