@@ -17,7 +17,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "diffusion-nlc_amd" / "csrc"
-OUT = ROOT / "diffusion-nlc_amd" / ("libnlc_hip_stamp_nostore.so" if os.environ.get("STAMP_NOSTORE") else "libnlc_hip_stamp.so")
+OUT = ROOT / "diffusion-nlc_amd" / ("libnlc_hip_stamp_nostore.so" if os.environ.get("STAMP_NOSTORE") else "libnlc_hip_stamp%s.so" % os.environ.get("STAMP_KT", ""))
 NSLOT = 16
 
 
@@ -73,6 +73,38 @@ def patched_source() -> str:
     if os.environ.get("STAMP_NOSTORE"):
         sub("                    *reinterpret_cast<uint4*>(op) = pk0;\n                    *reinterpret_cast<uint4*>(op + 8) = pk1;",
             "                    if (p.B < 0) { *reinterpret_cast<uint4*>(op) = pk0;\n                    *reinterpret_cast<uint4*>(op + 8) = pk1; }")
+    if os.environ.get("STAMP_STEPS"):
+        # per-k-step histogram (36 steps of a 256-channel tile): running sums in 2 KiB of LDS behind the kernel's own, lane 0 of waves 0 / 4
+        sub("constexpr int HALO_LDS = 2 * A_STAGE + NBST * B_STAGE + SCRATCH + 2 * COEF_STAGE;",
+            "constexpr int HALO_LDS_K = 2 * A_STAGE + NBST * B_STAGE + SCRATCH + 2 * COEF_STAGE;\nconstexpr int HALO_LDS = HALO_LDS_K + 2048;")
+        sub("    auto epilogue = [&](const TileH& t, const TileH& nx, bool has_next) {",
+            "    unsigned long long* st_steps = reinterpret_cast<unsigned long long*>(smem + HALO_LDS_K) + (wave >> 2) * 64;\n"
+            "    if ((wave & 3) == 0 && lane < 64) st_steps[lane] = 0;\n    unsigned long long st_prev = 0;\n"
+            "    auto epilogue = [&](const TileH& t, const TileH& nx, bool has_next) {")
+        sub("    constexpr int wdist = 3;", "    st_prev = now();\n    constexpr int wdist = 3;")
+        sub("                bcur = bnext;\n                ++kt;",
+            "                if ((wave & 3) == 0 && lane == 0 && kt < 64) { unsigned long long t = now(); st_steps[kt] += t - st_prev; st_prev = t; }\n"
+            "                bcur = bnext;\n                ++kt;")
+        sub("        st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1;",
+            "        st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1;\n"
+            "        if ((wave & 3) == 0 && lane == 0) { st_steps[63] += st_t0 - st_prev; st_prev = st_t0; }")
+        sub("    dma_wait_h<0>();          // the redundant tail fetches",
+            "    dma_wait_h<0>();          // the redundant tail fetches\n"
+            "    if ((wave == 0 || wave == 4) && lane < 64) g_steps[(blockIdx.x * 2 + (wave >> 2)) * 64 + lane] = st_steps[lane];")
+        sub("__device__ unsigned long long g_stamps[",
+            "__device__ unsigned long long g_steps[256 * 2 * 64];\n"
+            "extern \"C\" int nlc_debug_read_steps(void* dst, int bytes) {\n"
+            "    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_steps), bytes, 0, hipMemcpyDeviceToHost); }\n"
+            "__device__ unsigned long long g_stamps[")
+    skt = int(os.environ.get("STAMP_KT", "0"))
+    if skt:
+        # the in-step stamps (slots 8-11, 13) on k-step STAMP_KT (a multiple of 9: tap 0 of a later channel block) instead of step 0,
+        # measured from the barrier that ended the step before it (slot 14 = that whole step)
+        s = s.replace("if constexpr (tap == 0) { if (kt == 0) st_acc[", "if constexpr (tap == %d) { if (kt == %d) st_acc[" % (skt % 9, skt))
+        sub("                bcur = bnext;\n                ++kt;",
+            "                if constexpr (tap == %d) { if (kt == %d) st_t0 = now(); }\n"
+            "                if constexpr (tap == %d) { if (kt == %d) st_acc[14] += now() - st_t0; }\n"
+            "                bcur = bnext;\n                ++kt;" % ((skt - 1) % 9, skt - 1, skt % 9, skt))
     # start-of-kernel time + final write-out
     sub("    constexpr int wdist = 3;", "    st_t0 = now();\n    constexpr int wdist = 3;")
     sub("    dma_wait_h<0>();          // the redundant tail fetches",
@@ -124,7 +156,18 @@ def run(H=256, cin=256, cout=256, res=False, x3=False):
     rc = lib.nlc_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
     assert rc == 0, rc
     a = buf.reshape(256, 2, NSLOT).astype(np.float64)      # (last launch only: every launch overwrites)
-    names = ["k-loop", "epilogue (all of it)", "-", "-", "first k-step after epilogue", "k-step 4 of the tile", "k-steps 1 + 2 of the tile", "(tiles)", "step 0: first cluster issued", "step 0: + DMA issued", "step 0: + second cluster issued", "step 0: + counted wait", "loop top (next tile decoded)", "step 0: second-half fragments read"]
+    names = ["k-loop", "epilogue (all of it)", "-", "-", "first k-step after epilogue", "k-step 4 of the tile", "k-steps 1 + 2 of the tile", "(tiles)", "step 0: first cluster issued", "step 0: + DMA issued", "step 0: + second cluster issued", "step 0: + counted wait", "loop top (next tile decoded)", "step 0: second-half fragments read", "step STAMP_KT, whole"]
+    if os.environ.get("STAMP_STEPS"):
+        sb = np.zeros(256 * 2 * 64, dtype=np.uint64)
+        assert lib.nlc_debug_read_steps(sb.ctypes.data_as(ctypes.c_void_p), sb.nbytes) == 0
+        sb = sb.reshape(256, 2, 64).astype(np.float64)
+        nk = cin // 64 * 9
+        for wv in range(2):
+            per = np.median(sb[:, wv, :] / np.maximum(a[:, wv, 7:8], 1), axis=0)
+            print(f"wave {wv * 4}: cycles per k-step (median over workgroups, mean over tiles; step = barrier to barrier; 'ep' = end of the last step to the end of the epilogue)")
+            for c in range(nk // 9):
+                print("   block %d: " % c + " ".join(f"{per[c * 9 + t]:6.0f}" for t in range(9)))
+            print(f"   ep: {per[63]:6.0f}   sum of steps {per[:nk].sum():.0f}")
     for wv in range(2):
         tiles = a[:, wv, 7]
         print(f"wave {wv * 4}: tiles per workgroup {tiles.mean():.1f}")
