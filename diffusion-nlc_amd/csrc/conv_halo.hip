@@ -418,7 +418,35 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // goes out at the START of the epilogue, ahead of the stores (its stage was freed by the last step's barrier), step 0 issues none,
     // and the counted waits of steps 0 and 1 leave the eight row stores in flight: the first wait that covers them is step 2's, three
     // k-steps after they were issued.  post_ep: 2 / 1 = step 0 / 1 of a tile that follows such an epilogue (wave-uniform).
-    constexpr bool EARLY_W = FOLD && !SPLIT && !has_xf;
+    // DEFER (the CF instantiation): the eight row stores of a tile are not issued by its epilogue at all.  A 1-KiB store instruction
+    // holds its wave until the CU's store path has taken the data (64 KiB per tile from eight waves in lockstep: the epilogue ran 3.6 k
+    // cycles in the first wave and 5.9 k in the last, and the first k-step of the next tile another 1.7-3.9 k over a plain step while
+    // the early finishers waited at its barrier - tools/halo_stamps.py STAMP_STEPS=1; no MFMA runs meanwhile).  The packed rows stay in
+    // 32 registers and go out ONE per k-step, behind that step's DMA issue, under the next tile's steps 0-7 (a tile has >= 9); the
+    // last tile of a workgroup stores at once.  `pend`: 0 = nothing pending, 1 = rows pending, 2 = rows pending and ONE statistics
+    // atomic sits in the queue between the bias loads and step 0's DMA.  Every counted wait of those steps allows for the rows issued
+    // since the weight tile it is for: per step (issue order: weights, halo pieces, row)
+    //   step 0: [atomic] W3 h h r0 | wait for W2 (older than all of them)          -> allowance + 1 (+ 1 with the atomic)
+    //   step s = 1..7: ... r(s-1) W(s+3) [h h] r(s) | wait for W(s+2), issued before r(s-1)   -> allowance + 2
+    //   step 8: ... r7 W11 | wait for W10                                           -> allowance + 1
+    // (a second, poisoning atomic - non-finite outputs - only makes step 0's wait stricter than it needs to be).  With the rows out
+    // of the way the early weight issue below has nothing left to overtake and is off in this instantiation.
+    constexpr bool DEFER = CF;
+    constexpr bool peel_first = DEFER;       // (dispatch: CF launches have >= 2 channel blocks, no segment boundary behind the first, NHWC output, no activation)
+    constexpr bool EARLY_W = FOLD && !SPLIT && !has_xf && !DEFER;
+    int pend = 0;
+    uint4 pend0 = uint4{0, 0, 0, 0}, pend1 = pend0, pend2 = pend0, pend3 = pend0, pend4 = pend0, pend5 = pend0, pend6 = pend0, pend7 = pend0;   // (named: as an array they went to scratch)
+    auto pend_ref = [&](auto k_c) -> uint4& {
+        constexpr int k = decltype(k_c)::value;
+        if constexpr (k == 0) return pend0; else if constexpr (k == 1) return pend1; else if constexpr (k == 2) return pend2; else if constexpr (k == 3) return pend3;
+        else if constexpr (k == 4) return pend4; else if constexpr (k == 5) return pend5; else if constexpr (k == 6) return pend6; else return pend7;
+    };
+    T* pend_op = nullptr;
+    auto res_ptr = [&](const TileH& t, int i) -> const T* {            // row i of this lane's four, its 16 channels
+        const int n = t.n0 + wn * 64 + fq * 16;
+        if (!p.res_ups) return reinterpret_cast<const T*>(p.res) + ((((int64_t)t.tb * p.Hout + t.y0 + wm * 4 + i) * p.Wout + t.x0 + fr) * p.Cout + n);
+        return reinterpret_cast<const T*>(p.res) + res_row(p, t.tb, t.y0 + wm * 4 + i, t.x0 + fr) * p.Cout + n;
+    };
     int post_ep = 0;
     int bcur = 0, hs = 0;                            // weight stage / halo stage of the current k-step (run across tiles)
     auto epilogue = [&](const TileH& t, const TileH& nx, bool has_next) {
@@ -572,68 +600,85 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             // measured with stamps, the general path below spent ~9 k cycles per tile on ~19 VALU per output element
             // (no fused activation here: in the networks only the 1x1 "linear" layers carry one, and with both activations' code in this
             //  path the compiler merged three variants' registers with a shuffle per stored dword; the general path below has them)
-            if (vec_ok && t.n0 + BN <= p.Cout && p.out_mode == NLC_OUT_NHWC && p.act == NLC_ACT_NONE) {      // workgroup-uniform
+            if (DEFER || (vec_ok && t.n0 + BN <= p.Cout && p.out_mode == NLC_OUT_NHWC && p.act == NLC_ACT_NONE)) {      // workgroup-uniform
                 const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
                 const float sc = p.out_scale;
-                // all eight residual chunks are requested before the first row is stored (the output may alias nothing the compiler can
-                // see, so it kept each row's loads behind the previous row's stores: four exposed memory latencies per tile)
                 // row i of the lane's four is one image row further down: one address per tile, then a constant stride
                 const int64_t m0 = ((int64_t)t.tb * p.Hout + t.y0 + wm * 4) * p.Wout + t.x0 + fr;
                 const int64_t rstride = (int64_t)p.Wout * p.Cout;
                 T* const op0 = reinterpret_cast<T*>(p.out) + m0 * p.Cout + n;
-                uint4 rq0[4], rq1[4];
-                if (has_res) {
-                    if (!p.res_ups) {
-                        const T* rp0 = reinterpret_cast<const T*>(p.res) + m0 * p.Cout + n;
+                // DF: the rows stay in registers (pend0..7, stored under the next tile); with no store in the block the residual is requested
+                // two rows ahead of its use (16 fewer registers beside the pending rows).  Otherwise the rows are stored here, and all eight residual
+                // chunks are requested before the first store (the output may alias nothing the compiler can see, so it kept each row's
+                // loads behind the previous row's stores: four exposed memory latencies per tile).
+                auto hot = [&](auto df_c) {
+                    constexpr bool DF = decltype(df_c)::value;
+                    uint4 rq0[4], rq1[4];
+                    if (has_res) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            rq0[i] = *reinterpret_cast<const uint4*>(rp0 + i * rstride);
-                            rq1[i] = *reinterpret_cast<const uint4*>(rp0 + i * rstride + 8);
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const T* rp = reinterpret_cast<const T*>(p.res) + res_row(p, t.tb, t.y0 + wm * 4 + i, t.x0 + fr) * p.Cout + n;
+                        for (int i = 0; i < (DF ? 2 : 4); ++i) {
+                            const T* rp = res_ptr(t, i);
                             rq0[i] = *reinterpret_cast<const uint4*>(rp);
                             rq1[i] = *reinterpret_cast<const uint4*>(rp + 8);
                         }
                     }
-                }
+                    auto row = [&](auto i_c) {
+                        constexpr int i = decltype(i_c)::value;
+                        if constexpr (DF && i < 2) {
+                            if (has_res) {
+                                const T* rp = res_ptr(t, i + 2);
+                                rq0[i + 2] = *reinterpret_cast<const uint4*>(rp);
+                                rq1[i + 2] = *reinterpret_cast<const uint4*>(rp + 8);
+                            }
+                        }
+                        float v[16];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v[16];
+                        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                            for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg];
+                        if (has_res) {
+                            const uint4 r0 = rq0[i], r1 = rq1[i];
+                            float rr[16];
+                            chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
 #pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) v[j * 4 + reg] = acc[i][j][reg];
-                    if (has_res) {
-                        const uint4 r0 = rq0[i], r1 = rq1[i];
-                        float rr[16];
-                        chunk_to_f32<T>(r0, rr); chunk_to_f32<T>(r1, rr + 8);
+                            for (int k = 0; k < 16; ++k) v[k] += rr[k];
+                        }
+                        if (sc != 1.0f) {
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) v[k] += rr[k];
+                            for (int k = 0; k < 16; ++k) v[k] *= sc;
+                        }
+                        const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
+                        if constexpr (DF) {
+                            pend_ref(std::integral_constant<int, 2 * i>{}) = pk0; pend_ref(std::integral_constant<int, 2 * i + 1>{}) = pk1;
+                        } else {
+                            T* op = op0 + i * rstride;
+                            *reinterpret_cast<uint4*>(op) = pk0;
+                            *reinterpret_cast<uint4*>(op + 8) = pk1;
+                        }
+                        if (has_stats) {     // of the STORED (rounded) values - what the GroupNorm that follows reads
+                            st16.add_chunk<T>(0, pk0); st16.add_chunk<T>(1, pk1);
+                        }
+                    };
+                    row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+                    if (has_stats) emit_stats(st16, t, n);
+                    // the next tile's accumulators, initialised INSIDE this straight-line block: at the common tail below the wait-count
+                    // pass has to merge every epilogue variant and drains the counter (vmcnt(0): all eight store acknowledgements + the DMA)
+                    if constexpr (cfast) {
+                        // in order behind the bias (and embedding) loads: this block's eight row stores, or none (DF); + its statistics atomic
+                        if constexpr (DF) {
+                            if (has_stats) cadd_wait(std::integral_constant<int, 1>{}, cq, eq, cnext);
+                            else cadd_wait(std::integral_constant<int, 0>{}, cq, eq, cnext);
+                            pend = has_stats ? 2 : 1;
+                            pend_op = op0;
+                        } else {
+                            cadd_wait(std::integral_constant<int, 8>{}, cq, eq, cnext);
+                        }
                     }
-                    if (sc != 1.0f) {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) v[k] *= sc;
-                    }
-                    T* op = op0 + i * rstride;
-                    const uint4 pk0 = f32_to_chunk<T>(v), pk1 = f32_to_chunk<T>(v + 8);
-                    *reinterpret_cast<uint4*>(op) = pk0;
-                    *reinterpret_cast<uint4*>(op + 8) = pk1;
-                    if (has_stats) {     // of the STORED (rounded) values - what the GroupNorm that follows reads
-                        st16.add_chunk<T>(0, pk0); st16.add_chunk<T>(1, pk1);
-                    }
-                }
-                if (has_stats) emit_stats(st16, t, n);
-                // the next tile's accumulators, initialised INSIDE this straight-line block: at the common tail below the wait-count
-                // pass has to merge every epilogue variant and drains the counter (vmcnt(0): all eight store acknowledgements + the DMA)
-                if constexpr (cfast) {
-                    // in order behind the bias (and embedding) loads: exactly this block's eight row stores (+ its statistics stores)
-                    cadd_wait(std::integral_constant<int, 8>{}, cq, eq, cnext);
-                }
+                };
+                hot(std::integral_constant<bool, DEFER>{});
                 init_acc(cnext);
                 pin_acc();
+                if constexpr (DEFER) return;               // (the dispatch guarantees this path's conditions: no other epilogue code in the CF instantiation)
                 done = true;
                 inited = true;
             }
@@ -819,8 +864,12 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
         const bool has_next = tl + gx < chunk_len;
         int kt = 0;
         const int c_end = t_cb1(cur), nkt = t_nk(cur);
-        for (int cb = t_cb0(cur); cb < c_end; ++cb) {
-            const bool last_cb = cb + 1 == c_end;
+        // One channel block = nine k-steps.  FIRST (DEFER only): the copy of the body that a tile's first block runs when the previous
+        // tile left its rows pending - it is never the tile's last block and has no segment boundary behind it (peel_first), so the
+        // next-tile halo addressing (~60 registers of temporaries) is not in it, and the pending rows (34 registers) are in no other copy.
+        auto block = [&](const int cb, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            const bool last_cb = FIRST ? false : cb + 1 == c_end;
             const bool more = !last_cb || has_next;  // a halo follows this one in the stream
             auto step = [&](auto tap_c) {
                 constexpr int tap = decltype(tap_c)::value;
@@ -849,6 +898,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                                 // speculatively - to the top of every tile, between the epilogue and the first MFMA (tools/halo_stamps.py:
                                 // ~2.6 k cycles there); here it runs between two MFMA clusters of a step.  A next list entry on the same
                                 // patch (the other N-tile: N-tile fastest) keeps the addresses it has.
+                                if constexpr (!FIRST) {
                                 if (last_cb) {
                                     if (p.C1 > 0 || nxt.tb != cur.tb || nxt.y0 != cur.y0 || nxt.x0 != cur.x0) {
                                         TileH tn = nxt;
@@ -859,6 +909,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                                     TileH tn = cur;
                                     asm volatile("" : "+s"(tn.tb), "+s"(tn.y0), "+s"(tn.x0));
                                     halo_addr(tn, 1);
+                                }
                                 }
                                 if (coef_wave) issue_coef(last_cb ? 0 : cb + 1, hs ^ 1);     // BEFORE the halo rows: retired first
                             }
@@ -933,6 +984,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // starts with matrix work that is already in registers, and the first-dispatched waves 0-3 (which run
                 // ahead of their SIMD partners by ~150 cycles after every barrier) issue while waves 4-7 still compute.
                 issue_dma();
+                if constexpr (FIRST && tap < 8) {
+                    if (pend) *reinterpret_cast<uint4*>(pend_op + (tap >> 1) * ((int64_t)p.Wout * p.Cout) + (tap & 1) * 8) = pend_ref(tap_c);   // row tap of the previous tile
+                }
                 xf_mid();
                 load_frags(fa0, fb0, nast, bnext, std::integral_constant<int, ntap>{}, K0{});   // next step's first half
                 mma16(fa1, fb1);
@@ -945,7 +999,19 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // retire weights kt+2; instructions younger than them may stay in flight:
                 // this step's weights kt+3 (NB) and the halo instructions issued at this step or the previous one
                 // (issue order per step: weights, then 2 halo instructions at taps 0-2)
-                if constexpr (tap == 0) {
+                if (FIRST && pend) {
+                    const int allow = (tap == 0 || tap == 3) ? (more ? NB + 2 : NB) : (tap == 1 || tap == 2) ? (more ? NB + 4 : NB) : NB;
+                    switch (allow + (tap == 0 ? pend : tap == 8 ? 1 : 2)) {          // (see DEFER above; pend = 1 + atomics)
+                        case NB + 1: dma_wait_h<NB + 1>(); break;
+                        case NB + 2: dma_wait_h<NB + 2>(); break;
+                        case NB + 3: dma_wait_h<NB + 3>(); break;
+                        case NB + 4: dma_wait_h<NB + 4>(); break;
+                        case NB + 5: dma_wait_h<NB + 5>(); break;
+                        default: dma_wait_h<NB + 6>(); break;
+                    }
+                    if constexpr (tap == 8) pend = 0;
+                }
+                else if constexpr (tap == 0) {
                     if (EARLY_W && post_ep == 2) {
                         // younger than the weights of step 2 (which this wait is for): the early weight tile, 8 row stores, this step's halo
                         if (more) dma_wait_h<NB + 8 + 2>(); else dma_wait_h<NB + 8>();
@@ -972,12 +1038,24 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
             hs ^= 1;
-        }
+        };
+        int cb = t_cb0(cur);
+        if constexpr (peel_first) { block(cb, std::true_type{}); ++cb; }
+        for (; cb < c_end; ++cb) block(cb, std::false_type{});
         epilogue(cur, nxt, has_next);                // registers -> global, asynchronous stores; no LDS, no barrier
         if (!has_next) break;
         cur = nxt;
         nxt = nxt2;
         tl += gx;
+    }
+    if constexpr (DEFER) {
+        if (pend) {               // the last tile's rows
+            const int64_t rstride = (int64_t)p.Wout * p.Cout;
+            *reinterpret_cast<uint4*>(pend_op) = pend0;               *reinterpret_cast<uint4*>(pend_op + 8) = pend1;
+            *reinterpret_cast<uint4*>(pend_op + rstride) = pend2;     *reinterpret_cast<uint4*>(pend_op + rstride + 8) = pend3;
+            *reinterpret_cast<uint4*>(pend_op + 2 * rstride) = pend4; *reinterpret_cast<uint4*>(pend_op + 2 * rstride + 8) = pend5;
+            *reinterpret_cast<uint4*>(pend_op + 3 * rstride) = pend6; *reinterpret_cast<uint4*>(pend_op + 3 * rstride + 8) = pend7;
+        }
     }
     dma_wait_h<0>();          // the redundant tail fetches
 }
@@ -1065,7 +1143,9 @@ int nlc_conv_halo_dispatch(const KParams& p, int dtype, hipStream_t stream) {
     }
     if (!halo_plain_ok(p, dtype)) return NLC_EUNSUPPORTED;
     // CF instantiation: whole N-tiles, bias (and embedding) readable as aligned float4
+    const int kbe = MmaH<bf16_raw>::KBE;
     const bool cf = nlc_is16(dtype) && !p.gn_coef && (p.Cout % BN) == 0 && p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0 &&
+                    p.out_mode == NLC_OUT_NHWC && p.act == NLC_ACT_NONE && p.Cin_pad / kbe >= 2 && !(p.C1 > 0 && p.C0 / kbe == 1) &&
                     (!p.emb || ((reinterpret_cast<uintptr_t>(p.emb) & 15) == 0 && (p.emb_stride & 3) == 0));
     if (dtype == NLC_BF16) return p.gn_coef ? launch_halo<bf16_raw, true>(p, stream) : cf ? launch_halo<bf16_raw, false, false, false, true>(p, stream) : launch_halo<bf16_raw, false>(p, stream);
     if (dtype == NLC_F16) return cf ? launch_halo<f16_raw, false, false, false, true>(p, stream) : launch_halo<f16_raw, false>(p, stream);      // (GroupNorm prologue: bf16 instantiation only - it is off by default)

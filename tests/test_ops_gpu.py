@@ -951,14 +951,16 @@ def test_split_k_launches_leave_the_arrival_counters_zero():
 @pytest.mark.parametrize("with_emb", [False, True], ids=["bias", "bias+emb"])
 @pytest.mark.parametrize("with_res", [False, True], ids=["nores", "res"])
 def test_halo_conv_aligned_bias_instantiation_matches_the_general_one(dtype, with_emb, with_res):
-    """conv_halo_kernel's CF instantiation (whole N-tiles, 16-byte-aligned bias / embedding: explicit loads of the next tile's
-    initial accumulator values, counted waits, the next tile's weights issued ahead of the stores) must be bit-identical to the
-    general instantiation, which the same call takes when the bias pointer is not 16-byte aligned.  512 tiles on 256 persistent
-    workgroups: every workgroup crosses a tile boundary, half of them onto a new patch."""
+    """conv_halo_kernel's CF instantiation (whole N-tiles, >= 2 channel blocks, 16-byte-aligned bias / embedding: explicit loads of
+    the next tile's initial accumulator values, a tile's rows stored one per k-step under the NEXT tile's first channel block -
+    which runs a copy of the k-loop body of its own -, counted waits that allow for those stores, the last tile's rows flushed
+    behind the loop) must be bit-identical to the general instantiation, which the same call takes when the bias pointer is not
+    16-byte aligned.  768 tiles on 256 persistent workgroups: every workgroup crosses two tile boundaries (rows pending across
+    both), onto a new patch and onto the other N-tile of the same patch."""
     import dataclasses
     from diffusion_nlc_amd import ops
     g = torch.Generator().manual_seed(_seed(("cf", str(dtype), with_emb, with_res)))
-    B, Cin, H, Cout = 4, 64, 128, 256
+    B, Cin, H, Cout = 6, 128, 128, 256
     x = _nhwc(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
     b = torch.randn(Cout, generator=g) * 0.1

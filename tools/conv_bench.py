@@ -92,8 +92,16 @@ def main():
         res = torch.randn(args.batch, Ho, Ho, cout, device=dev).to(dt) if args.res else None
         tunings = [int(t) for t in args.tuning.split(",")]
         for _ in range(3):
-            ops.conv2d(x, pw, upsample2x=ups, res=res)
+            got = ops.conv2d(x, pw, upsample2x=ups, res=res)
         torch.cuda.synchronize()
+        if not args.zeros and k == 3 and args.policy == "auto":
+            # a schedule experiment that breaks the result must not pass as a timing: the same launch through the other 3x3 kernel
+            ops.CONV_POLICY = "no_halo"
+            ref = ops.conv2d(x, pw, upsample2x=ups, res=res, emit_stats=False).float()
+            ops.CONV_POLICY = args.policy
+            err, sc = (got.float() - ref).abs().max().item(), ref.abs().max().item()
+            assert err <= 2e-2 * sc, f"{note}: result differs from the no_halo dispatch by {err:.3e} (scale {sc:.3e})"
+            del ref
         fl = 2.0 * args.batch * H * H * cout * cin * k * k * (4 if ups else 1)
         times = {t: [] for t in tunings}
         for _ in range(args.rounds):                      # variants interleaved round by round in ONE process

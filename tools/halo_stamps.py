@@ -53,11 +53,16 @@ def patched_source() -> str:
         "                if constexpr (tap == 4) { if (kt == 4) st_acc[5] += now() - st_t1; }\n"
         "                bcur = bnext;\n                ++kt;")
     # inside step 0 of a tile (plain branch): after the DMA issue, after the second cluster's issue, after the counted wait, after the barrier
-    sub("                issue_dma();\n                xf_mid();\n                load_frags(fa0, fb0, nast, bnext",
+    sub("                issue_dma();\n                if constexpr (FIRST && tap < 8) {",
         "                if constexpr (tap == 0) { if (kt == 0) st_acc[8] += now() - st_t0; }\n"
-        "                issue_dma();\n                xf_mid();\n"
+        "                issue_dma();\n                if constexpr (FIRST && tap < 8) {")
+    sub("                xf_mid();\n                load_frags(fa0, fb0, nast, bnext",
+        "                xf_mid();\n"
         "                if constexpr (tap == 0) { if (kt == 0) st_acc[9] += now() - st_t0; }\n"
         "                load_frags(fa0, fb0, nast, bnext")
+    # the CF instantiation leaves its epilogue early
+    sub("                if constexpr (DEFER) return;",
+        "                if constexpr (DEFER) { st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1; STEPS_EP return; }")
     sub("                // retire weights kt+2; instructions younger than them may stay in flight:",
         "                if constexpr (tap == 0) { if (kt == 0) st_acc[10] += now() - st_t0; }\n"
         "                // retire weights kt+2; instructions younger than them may stay in flight:")
@@ -85,9 +90,10 @@ def patched_source() -> str:
         sub("                bcur = bnext;\n                ++kt;",
             "                if ((wave & 3) == 0 && lane == 0 && kt < 64) { unsigned long long t = now(); st_steps[kt] += t - st_prev; st_prev = t; }\n"
             "                bcur = bnext;\n                ++kt;")
-        sub("        st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1;",
+        sub("        st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1;\n",
             "        st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1;\n"
-            "        if ((wave & 3) == 0 && lane == 0) { st_steps[63] += st_t0 - st_prev; st_prev = st_t0; }")
+            "        if ((wave & 3) == 0 && lane == 0) { st_steps[63] += st_t0 - st_prev; st_prev = st_t0; }\n")
+        s = s.replace("STEPS_EP", "if ((wave & 3) == 0 && lane == 0) { st_steps[63] += st_t0 - st_prev; st_prev = st_t0; }")
         sub("    dma_wait_h<0>();          // the redundant tail fetches",
             "    dma_wait_h<0>();          // the redundant tail fetches\n"
             "    if ((wave == 0 || wave == 4) && lane < 64) g_steps[(blockIdx.x * 2 + (wave >> 2)) * 64 + lane] = st_steps[lane];")
@@ -105,6 +111,7 @@ def patched_source() -> str:
             "                if constexpr (tap == %d) { if (kt == %d) st_t0 = now(); }\n"
             "                if constexpr (tap == %d) { if (kt == %d) st_acc[14] += now() - st_t0; }\n"
             "                bcur = bnext;\n                ++kt;" % ((skt - 1) % 9, skt - 1, skt % 9, skt))
+    s = s.replace("STEPS_EP", "")
     # start-of-kernel time + final write-out
     sub("    constexpr int wdist = 3;", "    st_t0 = now();\n    constexpr int wdist = 3;")
     sub("    dma_wait_h<0>();          // the redundant tail fetches",
