@@ -185,6 +185,25 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             hvalid |= (ok ? 1u : 0u) << j;
         }
     };
+    // The same addresses moved by ONE wave-uniform byte distance (rows that point at the zero page stay there): what a change of tile
+    // comes to when the new patch touches the same image borders as the old one - source addresses are linear in (image, y, x) - and
+    // what a change of input segment comes to when both segments have the same channel count.  halo_addr costs ~3.8 k cycles where it
+    // runs (tap 0 of a tile's last channel block; 64-bit multiplies per row - tools/halo_stamps.py STAMP_STEPS=1); a persistent
+    // workgroup's next patch is 16 patches further on in the list, i.e. mostly straight down in the same image: 13 of 16 tile changes
+    // on a 256-wide map keep their border pattern.  This is six masked 64-bit adds.
+    auto halo_shift = [&](int64_t delta) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) haddr[j] = haddr[j] != zero ? haddr[j] + delta : haddr[j];
+    };
+    auto same_borders = [&](const TileH& a, const TileH& b) {       // wave-uniform
+        return ((a.y0 == 0) == (b.y0 == 0)) && ((a.y0 + PATCH == p.Hout) == (b.y0 + PATCH == p.Hout)) &&
+               ((a.x0 == 0) == (b.x0 == 0)) && ((a.x0 + PATCH == p.Wout) == (b.x0 + PATCH == p.Wout));
+    };
+    auto tile_distance = [&](const TileH& a, const TileH& b, int C) -> int64_t {       // bytes from a's halo rows to b's, same segment (wave-uniform)
+        const int sh = p.ups ? 1 : 0;
+        const int dpix = ((b.tb - a.tb) * p.Hin + ((b.y0 - a.y0) >> sh)) * p.Win + ((b.x0 - a.x0) >> sh);      // (multiples of 16: the shifts are exact)
+        return (int64_t)dpix * (int64_t)((unsigned)C * ES);
+    };
     const int64_t wrow = (int64_t)9 * p.Cin_pad * ES;
 
     // halo instructions [J0, J0 + N) of channel block cb (of the segment haddr was set up for)
@@ -903,12 +922,20 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                                     if (p.C1 > 0 || nxt.tb != cur.tb || nxt.y0 != cur.y0 || nxt.x0 != cur.x0) {
                                         TileH tn = nxt;
                                         asm volatile("" : "+s"(tn.tb), "+s"(tn.y0), "+s"(tn.x0));
-                                        halo_addr(tn, t_seg(nxt));
+                                        // (un-split tiles end in segment 1 of a concatenated input and start in segment 0)
+                                        if (!SPLIT && !has_gn && (p.C1 == 0 || p.C1 == p.C0) && same_borders(cur, tn))      // (has_gn: the coefficient rows move with the image too)
+                                            halo_shift(tile_distance(cur, tn, p.C0) + (p.C1 > 0 ? reinterpret_cast<const char*>(p.x0) - reinterpret_cast<const char*>(p.x1) : (int64_t)0));
+                                        else
+                                            halo_addr(tn, t_seg(nxt));
                                     }
                                 } else if (p.C1 > 0 && cb + 1 == cbs1) {
-                                    TileH tn = cur;
-                                    asm volatile("" : "+s"(tn.tb), "+s"(tn.y0), "+s"(tn.x0));
-                                    halo_addr(tn, 1);
+                                    if (p.C1 == p.C0 && !has_gn) {
+                                        halo_shift(reinterpret_cast<const char*>(p.x1) - reinterpret_cast<const char*>(p.x0));
+                                    } else {
+                                        TileH tn = cur;
+                                        asm volatile("" : "+s"(tn.tb), "+s"(tn.y0), "+s"(tn.x0));
+                                        halo_addr(tn, 1);
+                                    }
                                 }
                                 }
                                 if (coef_wave) issue_coef(last_cb ? 0 : cb + 1, hs ^ 1);     // BEFORE the halo rows: retired first

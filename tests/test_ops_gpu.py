@@ -985,6 +985,38 @@ def test_halo_conv_aligned_bias_instantiation_matches_the_general_one(dtype, wit
     _close(ya.permute(0, 3, 1, 2), ref.cpu(), _tol(dtype), "CF halo conv")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("ups", [False, True], ids=["plain", "ups2x"])
+@pytest.mark.parametrize("split", [None, (128, 128), (192, 64)], ids=["one-input", "cat-128+128", "cat-192+64"])
+@pytest.mark.parametrize("shape", [(6, 128, 128), (3, 64, 256)], ids=["6x128x128", "3x64x256"])
+def test_halo_conv_tile_and_segment_changes(dtype, ups, split, shape):
+    """A persistent halo workgroup re-targets its halo source addresses at every change of patch and, on a concatenated input, of
+    input segment: by one uniform distance where the new patch touches the same image borders (and the two segments have the same
+    channel count), by the full per-row computation otherwise.  Several tiles per workgroup (768 / 384 on 256), every kind of
+    change among them - down inside an image, onto and off the top / bottom (and, on the wide map, left / right) borders, on to
+    the next image, segment 0 -> 1 -> 0 with equal and unequal channel counts, with and without the fused nearest-2x upsample -
+    against torch's convolution of the same (concatenated, upsampled) input."""
+    from diffusion_nlc_amd import ops
+    g = torch.Generator().manual_seed(_seed(("tile-changes", str(dtype), ups, split, shape)))
+    B, H, W = shape
+    Cin, Cout = 256, 256
+    hi, wi = (H // 2, W // 2) if ups else (H, W)
+    xf = torch.randn(B, Cin, hi, wi, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pw = ops.pack_conv(w, b, dtype, _dev())
+    if split is None:
+        x0, x1 = _nhwc(xf, dtype), None
+    else:
+        x0, x1 = _nhwc(xf[:, :split[0]], dtype), _nhwc(xf[:, split[0]:], dtype)
+    got = ops.conv2d(x0, pw, x1=x1, upsample2x=ups)
+    xin = _rt(xf, dtype)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin.to(_dev()), _rt(w, dtype).to(_dev()), b.to(_dev()), padding=1)
+    _close(got.permute(0, 3, 1, 2), ref.cpu(), _tol(dtype), "halo conv across tile / segment changes")
+
+
 def test_split_k_stress():
     """2 000 back-to-back split-K launches, mixed kernels and levels (halo kernel on the 16x16 level, conv_fast<9> on the 8x8 level,
     conv_fast<1>), through ONE workspace, half of them beside a second stream that keeps the memory system busy: every result is
