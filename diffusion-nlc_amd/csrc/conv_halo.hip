@@ -635,7 +635,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     uint4 rq0[4], rq1[4];
                     if (has_res) {
 #pragma unroll
-                        for (int i = 0; i < (DF ? 2 : 4); ++i) {
+                        for (int i = 0; i < 4; ++i) {
                             const T* rp = res_ptr(t, i);
                             rq0[i] = *reinterpret_cast<const uint4*>(rp);
                             rq1[i] = *reinterpret_cast<const uint4*>(rp + 8);
@@ -643,13 +643,6 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     }
                     auto row = [&](auto i_c) {
                         constexpr int i = decltype(i_c)::value;
-                        if constexpr (DF && i < 2) {
-                            if (has_res) {
-                                const T* rp = res_ptr(t, i + 2);
-                                rq0[i + 2] = *reinterpret_cast<const uint4*>(rp);
-                                rq1[i + 2] = *reinterpret_cast<const uint4*>(rp + 8);
-                            }
-                        }
                         float v[16];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)

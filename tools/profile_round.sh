@@ -12,7 +12,7 @@ echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/${tag}_step_fetch" -o f --output-format csv -- $B --steps 1 --warmup 0 --timesteps 2 > /dev/null 2> "$O/${tag}_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/${tag}_step_write" -o w --output-format csv -- $B --steps 1 --warmup 0 --timesteps 2 > /dev/null 2> "$O/${tag}_write.err"
 echo "step traffic done"
-C="python3 $R/tools/conv_bench.py --only 0 --reps 2 --rounds 1"
+C="python3 $R/tools/conv_bench.py --only 0 --reps 2 --rounds 1 --no-check"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/${tag}_dom_fetch" -o f --output-format csv -- $C > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/${tag}_dom_write" -o w --output-format csv -- $C > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$O/${tag}_dom_sq_a" -o a --output-format csv -- $C > /dev/null 2>&1
