@@ -412,19 +412,21 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
     };
-    // CF: counted wait for the explicit bias / embedding loads of the epilogue (N = vector-memory operations this path issued after
-    // them), then cnext = bias + embedding
-    auto cadd_wait = [&](auto n_c, f32x4_t (&cq)[4], f32x4_t (&eq)[4], float (&cnext)[16]) {
-        constexpr int N = decltype(n_c)::value;
+    // CF: cnext = bias + embedding from the epilogue's loads.  The loads are ordinary (compiler-visible) loads: the compiler's own
+    // wait-count pass then puts `s_waitcnt vmcnt(N)` in front of the FIRST instruction that touches their destination registers,
+    // with N = the vector-memory operations IT issued after them (the statistics atomic; the DMA in flight is older).  Until round 5
+    // they were inline-asm loads waited for by an inline-asm `s_waitcnt` with the registers as tied "+v" operands - and the register
+    // allocator, which cannot know that an asm output is not there yet, put COPIES of them (v_mov_b64) in front of that wait: reads
+    // of registers still in flight.  Harmless while eight row stores sat between the loads and the wait (the compiler's own store
+    // hazard wait happened to precede the copies); with the deferred rows nothing did, and whenever the bias vector missed in L2 the
+    // next tile started from garbage accumulators (sporadic, a whole XCD's round of tiles at a time: tests B <= 3 at 256 x 256).
+    auto cadd_sum = [&](const f32x4_t (&cq)[4], const f32x4_t (&eq)[4], float (&cnext)[16]) {
         if (p.emb) {
-            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(eq[0]), "+v"(eq[1]), "+v"(eq[2]), "+v"(eq[3])
-                         : "n"(N) : "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cnext[q * 4 + r] = cq[q][r] + eq[q][r];
         } else {
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]) : "n"(N) : "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -475,10 +477,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             if (early) issue_B(nx.n0, 0, 3, (bcur + 3) & 3);
         }
         float cnext[16];
-        // The next tile's bias vector, requested NOW so that it lands while this tile is stored.  As plain C++ loads the compiler sank
-        // them (and their wait) to the accumulator initialisation behind the stores - `s_waitcnt vmcnt(3..0)`: the load latency in the
-        // open and, the counter being in order, a drain of every store and DMA ahead of them.  So (16-bit, aligned bias, no embedding,
-        // whole 16-channel slices): four explicit global_load_dwordx4, and the wait below counts only what this path issued after them.
+        // The next tile's bias vector, requested NOW so that it lands while this tile's rows are converted.  Left alone the compiler sinks
+        // such loads (and their wait) to the accumulator initialisation at the end of the epilogue - the load latency in the open and, the
+        // counter being in order, a drain of every DMA ahead of them.  So (CF: 16-bit, aligned bias / embedding, whole 16-channel slices):
+        // four 16-byte loads per vector pinned here by an empty asm that clobbers memory, and consumed by cadd_sum (see there).
         f32x4_t cq[4], eq[4];
         constexpr bool cfast = CF;
         static_assert(!CF || (FOLD && !SPLIT && !has_xf), "CF: plain 16-bit kernel only");
@@ -488,20 +490,15 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             unsigned voff;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\t"
                          "v_lshrrev_b32 %0, 4, %0\n\tv_lshlrev_b32 %0, 6, %0" : "=v"(voff));
-            const float* sb = p.bias + nx.n0 + wn * 64;          // wave-uniform
-            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
-                         "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
-                         "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
-                         "global_load_dwordx4 %3, %4, %5 offset:48"
-                         : "=&v"(cq[0]), "=&v"(cq[1]), "=&v"(cq[2]), "=&v"(cq[3]) : "v"(voff), "s"(sb) : "memory");
+            const char* sb = reinterpret_cast<const char*>(p.bias + nx.n0 + wn * 64);          // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cq[q] = *reinterpret_cast<const f32x4_t*>(sb + voff + q * 16);
             if (p.emb) {
-                const float* se = p.emb + (int64_t)nx.tb * p.emb_stride + nx.n0 + wn * 64;
-                asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
-                             "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
-                             "global_load_dwordx4 %2, %4, %5 offset:32\n\t"
-                             "global_load_dwordx4 %3, %4, %5 offset:48"
-                             : "=&v"(eq[0]), "=&v"(eq[1]), "=&v"(eq[2]), "=&v"(eq[3]) : "v"(voff), "s"(se) : "memory");
+                const char* se = reinterpret_cast<const char*>(p.emb + (int64_t)nx.tb * p.emb_stride + nx.n0 + wn * 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) eq[q] = *reinterpret_cast<const f32x4_t*>(se + voff + q * 16);
             }
+            asm volatile("" ::: "memory");          // the loads stay HERE (requested while this tile's rows are converted), not at their use
         } else if constexpr (SPLIT) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) cnext[k] = 0.f;           // raw partial sums: bias / embedding are added by the last arriver
@@ -672,25 +669,28 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                         }
                     };
                     row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
-                    if (has_stats) emit_stats(st16, t, n);
+                    if constexpr (!DF) { if (has_stats) emit_stats(st16, t, n); }
                     // the next tile's accumulators, initialised INSIDE this straight-line block: at the common tail below the wait-count
                     // pass has to merge every epilogue variant and drains the counter (vmcnt(0): all eight store acknowledgements + the DMA)
                     if constexpr (cfast) {
                         // in order behind the bias (and embedding) loads: this block's eight row stores, or none (DF); + its statistics atomic
+                        cadd_sum(cq, eq, cnext);
                         if constexpr (DF) {
-                            if (has_stats) cadd_wait(std::integral_constant<int, 1>{}, cq, eq, cnext);
-                            else cadd_wait(std::integral_constant<int, 0>{}, cq, eq, cnext);
                             pend = has_stats ? 2 : 1;
                             pend_op = op0;
-                        } else {
-                            cadd_wait(std::integral_constant<int, 8>{}, cq, eq, cnext);
                         }
                     }
                 };
                 hot(std::integral_constant<bool, DEFER>{});
                 init_acc(cnext);
                 pin_acc();
-                if constexpr (DEFER) return;               // (the dispatch guarantees this path's conditions: no other epilogue code in the CF instantiation)
+                if constexpr (DEFER) {
+                    // the statistics atomic goes out BEHIND the use of the bias loads: the compiler's wait for those then counts nothing
+                    // younger (with the atomic ahead of it, in two branches - add / poison - it became vmcnt(0): the atomic's round trip)
+                    asm volatile("" ::: "memory");
+                    if (has_stats) emit_stats(st16, t, n);
+                    return;               // (the dispatch guarantees this path's conditions: no other epilogue code in the CF instantiation)
+                }
                 done = true;
                 inited = true;
             }
@@ -824,9 +824,7 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
             if constexpr (sizeof(T) == 2) {
                 if (p.stats && n + 16 <= p.Cout && !parked) emit_stats(st16, t, n);
             }
-            if constexpr (cfast) {     // (a path other than the vectorised one ran: unknown number of stores since the loads - drain)
-                cadd_wait(std::integral_constant<int, 0>{}, cq, eq, cnext);
-            }
+            if constexpr (cfast) cadd_sum(cq, eq, cnext);
             init_acc(cnext);
             pin_acc();
         }

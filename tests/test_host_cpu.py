@@ -317,3 +317,28 @@ def test_edm_pickle_reader_needs_no_dnnlib_and_executes_nothing(tmp_path):
         pickle.dump(dict(ema=Evil()), f)
     assert load_edm_pickle(evil, submodule="") == {}
     assert not (tmp_path / "pwned").exists()
+
+
+def test_inline_asm_loads_are_never_touched_in_flight(tmp_path):
+    """tools/asm_load_audit.py over the compiled gfx950 code of every kernel source that loads into registers from inline asm (the
+    sc1 read-backs of the split-K hand-offs): between such a load and a wait that covers it no instruction may read or write its
+    destination registers - the register allocator does not know that an asm output is still in flight and has put copies there
+    before (conv_halo's CF epilogue, round 5: fixed by making those loads compiler-visible).  hipcc cross-compiles without a GPU."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = Path(__file__).resolve().parent.parent
+    src = root / "diffusion-nlc_amd" / "csrc"
+    stems = ["conv_halo", "conv_fast", "conv_small"]
+    procs = [subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", f"-I{root / 'include'}", f"-I{src}", "-S",
+                               "--cuda-device-only", "-o", str(tmp_path / f"{s}.s"), str(src / f"{s}.hip")],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for s in stems]
+    for s, pr in zip(stems, procs):
+        _, err = pr.communicate(timeout=900)
+        assert pr.returncode == 0, f"{s}.hip: {err.decode()[-2000:]}"
+    r = subprocess.run([sys.executable, str(root / "tools" / "asm_load_audit.py")] + [str(tmp_path / f"{s}.s") for s in stems],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "0 touches" in r.stdout

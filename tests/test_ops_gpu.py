@@ -985,6 +985,45 @@ def test_halo_conv_aligned_bias_instantiation_matches_the_general_one(dtype, wit
     _close(ya.permute(0, 3, 1, 2), ref.cpu(), _tol(dtype), "CF halo conv")
 
 
+@pytest.mark.parametrize("B", [1, 2, 3])
+@pytest.mark.parametrize("cat", [False, True], ids=["one-input", "cat-256+256"])
+def test_halo_conv_next_tile_starts_from_landed_bias(B, cat):
+    """Regression (round 5): the CF halo kernel fetches the NEXT tile's bias (+ embedding) vector at the top of a tile's epilogue and
+    initialises the next tile's accumulators from it at the end.  While those were inline-asm loads the register allocator copied
+    their destination registers in front of the inline-asm wait, so a tile started from whatever the registers held whenever the
+    bias vector missed in L2 - seen on 256 x 256 maps at B <= 3 (2 ... 6 tiles per workgroup, short epilogues: deferred rows, no
+    residual), a whole XCD's round of tiles at a time, only with ride-along statistics on.  Every launch here gets a bias vector
+    of its own at a fresh address behind a cache-sweeping copy; compared with the other 3x3 kernel on the same operands
+    (tools/asm_load_audit.py checks the compiled code for the pattern itself; tests/test_host_cpu.py runs it)."""
+    from diffusion_nlc_amd import ops
+    import dataclasses
+    g = torch.Generator().manual_seed(_seed(("cold-bias", B, cat)))
+    H, Cout = 256, 256
+    c0, c1 = (256, 256) if cat else (256, 0)
+    x0 = _nhwc(torch.randn(B, c0, H, H, generator=g), torch.bfloat16)
+    x1 = _nhwc(torch.randn(B, c1, H, H, generator=g), torch.bfloat16) if c1 else None
+    w = torch.randn(Cout, c0 + c1, 3, 3, generator=g) / math.sqrt((c0 + c1) * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pw = ops.pack_conv(w, b, torch.bfloat16, _dev())
+    old = ops.CONV_POLICY
+    try:
+        ops.CONV_POLICY = "no_halo"
+        ref = ops.conv2d(x0, pw, x1=x1, emit_stats=False).float()
+        ops.CONV_POLICY = "auto"
+        sweep = torch.empty(96 << 20, device=_dev(), dtype=torch.uint8)
+        keep = []
+        for rep in range(6):
+            fresh = torch.empty(Cout + 64 * (rep + 1), device=_dev(), dtype=torch.float32)[:Cout]      # a new allocation each time
+            fresh.copy_(pw.bias)
+            keep.append(fresh)
+            sweep.fill_(rep)                                                                          # 96 MB through every L2
+            got = ops.conv2d(x0, dataclasses.replace(pw, bias=fresh), x1=x1, emit_stats=True).float()
+            d = (got - ref).abs()
+            assert int((d > 0.1).sum().item()) == 0, f"launch {rep}: {int((d > 0.1).sum().item())} outputs off by more than 0.1 (max {d.max().item():.3g})"
+    finally:
+        ops.CONV_POLICY = old
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 @pytest.mark.parametrize("ups", [False, True], ids=["plain", "ups2x"])
 @pytest.mark.parametrize("split", [None, (128, 128), (192, 64)], ids=["one-input", "cat-128+128", "cat-192+64"])
