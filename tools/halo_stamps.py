@@ -61,8 +61,9 @@ def patched_source() -> str:
         "                if constexpr (tap == 0) { if (kt == 0) st_acc[9] += now() - st_t0; }\n"
         "                load_frags(fa0, fb0, nast, bnext")
     # the CF instantiation leaves its epilogue early
-    sub("                if constexpr (DEFER) return;",
-        "                if constexpr (DEFER) { st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1; STEPS_EP return; }")
+    sub("                    if (has_stats) emit_stats(st16, t, n);\n                    return;",
+        "                    if (has_stats) emit_stats(st16, t, n);\n"
+        "                    st_t0 = now(); st_acc[1] += st_t0 - st_t1; st_acc[7] += 1; STEPS_EP return;")
     sub("                // retire weights kt+2; instructions younger than them may stay in flight:",
         "                if constexpr (tap == 0) { if (kt == 0) st_acc[10] += now() - st_t0; }\n"
         "                // retire weights kt+2; instructions younger than them may stay in flight:")
