@@ -125,6 +125,32 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     int tl = wi;
     if (tl >= chunk_len) return;                     // workgroup-uniform
     TileH cur = decode(tl);
+    // A workgroup's next list entry is always `gx` entries further on: instead of decoding it (three dependent integer divisions by
+    // run-time divisors, ~0.7 k cycles of a k-step with both waves of a SIMD in the same scalar code - tools/halo_stamps.py
+    // STAMP_STEPS=1, tap 4 of a tile's first block) the un-split instantiations ADD the stride, decomposed once into the list's mixed
+    // radix (N-tile fastest, then patch column, patch row, image), with one conditional subtraction per digit.
+    int adv_n0 = 0, adv_x0 = 0, adv_y0 = 0, adv_tb = 0;
+    if constexpr (!SPLIT) {
+        const int c1 = gx / p.NT, c2 = c1 / tiles_x;
+        adv_n0 = (gx - c1 * p.NT) * BN;
+        adv_x0 = (c1 - c2 * tiles_x) * PATCH;
+        adv_tb = c2 / tiles_y;
+        adv_y0 = (c2 - adv_tb * tiles_y) * PATCH;
+    }
+    auto advance = [&](const TileH& t) {             // the entry gx further on (un-split lists; wave-uniform)
+        TileH r = t;
+        r.n0 += adv_n0;
+        int carry = r.n0 >= p.NT * BN ? 1 : 0;
+        r.n0 -= carry ? p.NT * BN : 0;
+        r.x0 += adv_x0 + carry * PATCH;
+        carry = r.x0 >= p.Wout ? 1 : 0;
+        r.x0 -= carry ? p.Wout : 0;
+        r.y0 += adv_y0 + carry * PATCH;
+        carry = r.y0 >= p.Hout ? 1 : 0;
+        r.y0 -= carry ? p.Hout : 0;
+        r.tb += adv_tb + carry;
+        return r;
+    };
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -866,8 +892,9 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
     // (Tried and measured slower on this kernel, 1.18 vs 1.12 ms on 256->256 @256^2: running SIMD partner waves in
     //  complementary orders by giving waves 0-3 / 4-7 their barrier at different points of one instruction stream.)
     constexpr int wdist = 3;                         // weight tiles run 3 k-steps ahead
-    // The list entry after next is decoded (five integer divisions, ~1 k cycles of dependent scalar work) inside the current tile's
-    // k-loop, where the matrix pipe covers it; at the top of a tile it sat between the epilogue and the first MFMA.
+    // The list entry after next is worked out inside the current tile's k-loop (tap 4 of its first block), not at the top of a tile
+    // between the epilogue and the first MFMA: by `advance` (a dozen scalar operations), or - split lists - by a full decode (five
+    // integer divisions, ~1 k cycles of dependent scalar work, of which ~0.7 k showed as extra time of that k-step).
     TileH nxt = tl + gx < chunk_len ? decode(tl + gx) : cur;
     TileH nxt2 = nxt;
     for (;;) {
@@ -893,7 +920,10 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                 // stale-but-valid LDS; neither result is used (straight-line body, no data-dependent branches).
                 auto issue_dma = [&]() {
                     if constexpr (tap == 4) {
-                        if (kt == 4) nxt2 = tl + 2 * gx < chunk_len ? decode(tl + 2 * gx) : nxt;       // workgroup-uniform
+                        if (kt == 4) {                                                                 // workgroup-uniform
+                            if constexpr (SPLIT) nxt2 = tl + 2 * gx < chunk_len ? decode(tl + 2 * gx) : nxt;
+                            else nxt2 = tl + 2 * gx < chunk_len ? advance(nxt) : nxt;
+                        }
                     }
                     const int k3 = kt + wdist;
                     const bool wrap = k3 >= nkt;

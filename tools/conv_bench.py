@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--res", action="store_true", help="with a residual input (the second conv of a ResBlock)")
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights: same instruction stream, least energy per MFMA "
                     "(what the clock does to the rate: MI355X_MICROARCH.md 'DVFS give-back')")
+    ap.add_argument("--no-stats", action="store_true", help="launch without ride-along GroupNorm statistics (what the epilogue's statistics work costs)")
     ap.add_argument("--no-check", action="store_true", help="skip the comparison with the no_halo dispatch (counter passes: no other kernel in the trace)")
     ap.add_argument("--shape", action="append", default=[], help="extra shape H,Cin,Cout,k (replaces the list; may repeat)")
     args = ap.parse_args()
@@ -92,8 +93,9 @@ def main():
         Ho = 2 * H if ups else H
         res = torch.randn(args.batch, Ho, Ho, cout, device=dev).to(dt) if args.res else None
         tunings = [int(t) for t in args.tuning.split(",")]
+        st = not args.no_stats
         for _ in range(3):
-            got = ops.conv2d(x, pw, upsample2x=ups, res=res)
+            got = ops.conv2d(x, pw, upsample2x=ups, res=res, emit_stats=st)
         torch.cuda.synchronize()
         if not args.zeros and not args.no_check and k == 3 and args.policy == "auto":
             # a schedule experiment that breaks the result must not pass as a timing: the same launch through the other 3x3 kernel
@@ -111,7 +113,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.reps):
-                    ops.conv2d(x, pw, upsample2x=ups, res=res)
+                    ops.conv2d(x, pw, upsample2x=ups, res=res, emit_stats=st)
                 e1.record()
                 torch.cuda.synchronize()
                 times[t].append(e0.elapsed_time(e1) / args.reps)
