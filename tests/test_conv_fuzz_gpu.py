@@ -2,7 +2,8 @@
 small-map with or without split-K, conv_fast, resident / streaming pointwise, generic - and how many tiles each persistent workgroup
 walks is a function of (batch, map size, channels, concatenation, stride, fused upsample, residual, embedding, statistics), and the
 benchmark's shapes visit only a few points of that space, all of them with whole rounds of tiles.  Every case here is launched twice
-(a 64 MB fill in between: cold weights / bias) - the two results must be BIT-IDENTICAL, fixed summation orders everywhere - and is
+(a 64 MB fill in between: cold weights / bias) and a third time beside a second stream that hammers the memory system - all three
+results must be BIT-IDENTICAL, fixed summation orders everywhere (a counted wait that allows one operation too many shows here) - and is
 compared with the library's exact-f32 generic kernel on the operands as rounded to the compute dtype (itself checked against torch's
 CPU convolution on the cases below 30 GFLOP), the ride-along GroupNorm totals with the sums of the stored output in f64.
 
@@ -44,6 +45,25 @@ def _cases(n, seed=20261005):
     return out
 
 
+_STATE = {}
+
+
+def _same(a, b) -> bool:          # (a plain bool: pytest's assertion rewriting would otherwise print both tensors)
+    return bool(torch.equal(a, b))
+
+
+def _side():
+    if "side" not in _STATE:
+        _STATE["side"] = torch.cuda.Stream()
+    return _STATE["side"]
+
+
+def _hog():
+    if "hog" not in _STATE:
+        _STATE["hog"] = torch.empty(256 << 20, device=DEV, dtype=torch.uint8)
+    return _STATE["hog"]
+
+
 def _run_case(c, sweep):
     from diffusion_nlc_amd import ops
     dt = torch.bfloat16 if c["dtype"] == "bf16" else torch.float16
@@ -63,7 +83,19 @@ def _run_case(c, sweep):
         sweep.fill_(rep)
         y = ops.conv2d(x0, pw, x1=x1, stride=s, upsample2x=c["ups"], res=res, emb=emb, emit_stats=c["stats"])
         outs.append((y, getattr(y, "_nlc_stats", None)))
-    assert torch.equal(outs[0][0], outs[1][0]), "two identical launches differ"
+    assert _same(outs[0][0], outs[1][0]), "two identical launches differ"
+    # ... and a third one beside a second stream that keeps the memory system busy (fills of a 256 MB buffer; they need no LDS, so they
+    # share the CUs with the convolution's workgroups): every DMA and load of the launch takes longer and lands in a different order
+    side = _side()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for rep in range(3):
+            _hog().fill_(rep)
+    y3 = ops.conv2d(x0, pw, x1=x1, stride=s, upsample2x=c["ups"], res=res, emb=emb, emit_stats=c["stats"])
+    torch.cuda.current_stream().wait_stream(side)
+    assert _same(y3, outs[0][0]), "a launch beside a busy second stream differs from the undisturbed one"
+    if outs[0][1] is not None:
+        assert _same(getattr(y3, "_nlc_stats"), outs[0][1]), "ride-along totals differ beside a busy second stream"
     if outs[0][1] is not None:
         assert outs[1][1] is not None and torch.equal(outs[0][1], outs[1][1]), "ride-along totals of two identical launches differ"
     y, st = outs[0]
