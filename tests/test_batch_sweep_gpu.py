@@ -7,8 +7,9 @@ only at 2 ... 6 tiles per workgroup and only when a bias vector missed in L2; it
 the one full-size test that happened to run at B = 2.  So: every network, forward and encode (+ sigma net), at batch sizes that give
 ragged tile counts, in the benchmarked precision -
 
-  * evaluated three times, each after a cache-sweeping fill: the 16-bit path uses fixed summation orders everywhere, so the three
-    results must be BIT-IDENTICAL (a timing-dependent fault shows as a mismatch);
+  * evaluated three times, each after a cache-sweeping fill, and a fourth time beside a second stream that hammers the memory system: the
+    16-bit path uses fixed summation orders everywhere, so the four results must be BIT-IDENTICAL (a timing-dependent fault - a counted
+    wait that allows one operation too many, a register read before its load has landed - shows as a mismatch);
   * against the f32 path of the same kernels (exact-f32 MFMA, no split-K, Chan-merged statistics): relative RMS <= 2e-2 and
     L-inf <= 8e-2 of the f32 output's scale, the per-evaluation error of bf16 operands; the sigma head (a log-ratio of
     order 0.01 ... 0.1 with these weights) within 1e-2 absolute (observed <= 3.2e-3 under every dispatch, the generic kernel included).
@@ -66,6 +67,8 @@ def test_ragged_batches_are_reproducible_and_track_f32(nets):
     import bench
     kind, eps, sig, res = nets
     sweep = torch.empty(128 << 20, device=DEV, dtype=torch.uint8)
+    hog = torch.empty(256 << 20, device=DEV, dtype=torch.uint8)
+    side = torch.cuda.Stream()
     for B in BATCHES[kind]:
         g = torch.Generator().manual_seed(1000 + B)
         if kind == "edm32":
@@ -78,9 +81,18 @@ def test_ragged_batches_are_reproducible_and_track_f32(nets):
         for rep in range(3):
             sweep.fill_(rep + 1)                                                       # 128 MB through every L2: cold weights, bias, tables
             runs.append(_evaluate(kind, eps, sig, x, t))
-        for rep in (1, 2):
-            assert torch.equal(runs[rep][0], runs[0][0]), f"{kind} B={B}: forward differs between identical evaluations (run {rep})"
-            assert torch.equal(runs[rep][1], runs[0][1]), f"{kind} B={B}: sigma head differs between identical evaluations (run {rep})"
+        # ... and once beside a second stream that keeps the memory system busy for the whole evaluation (fills of a 256 MB buffer: no LDS,
+        # so they share the CUs with the persistent kernels' workgroups) - every DMA, load and atomic takes longer and lands in another order
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for rep in range(12 if kind == "adm256" else 6):
+                hog.fill_(rep)
+        runs.append(_evaluate(kind, eps, sig, x, t))
+        torch.cuda.current_stream().wait_stream(side)
+        for rep in (1, 2, 3):
+            same = bool(torch.equal(runs[rep][0], runs[0][0])), bool(torch.equal(runs[rep][1], runs[0][1]))
+            assert same[0], f"{kind} B={B}: forward differs between identical evaluations (run {rep}{' beside a busy stream' if rep == 3 else ''})"
+            assert same[1], f"{kind} B={B}: sigma head differs between identical evaluations (run {rep}{' beside a busy stream' if rep == 3 else ''})"
         for m in (eps, sig):
             bench.set_precision(m, bench.PRECISIONS["f32"])
         try:
