@@ -53,7 +53,7 @@ def nets(request):
     return (request.param,) + _models(request.param)
 
 
-BATCHES = {"adm256": [1, 2, 3, 5], "celebahq256": [1, 3, 5, 7], "edm32": [1, 7, 50, 200]}
+BATCHES = {"adm256": [1, 2, 3, 5, 16], "celebahq256": [1, 3, 5, 7, 8], "edm32": [1, 7, 50, 200]}          # (the last of each: the benchmark's own)
 
 
 def _evaluate(kind, eps, sig, x, t):
