@@ -1117,11 +1117,11 @@ int launch_halo(const KParams& p, hipStream_t stream) {
     const int ncu = once.ncu[slot];
     const int nblk = p.B * (p.Hout / PATCH) * (p.Wout / PATCH) * p.NT * (SPLIT ? p.ksplit : 1);
     int grid = nblk < ncu ? nblk : ncu;              // one persistent workgroup per CU (154 KiB of LDS each)
-    if (!(p.tuning & (1 << 24)) && nblk > ncu) {
+    if (!(p.tuning & (1 << 27)) && nblk > ncu) {
         // The fewest workgroups that finish in the same number of rounds, in whole multiples of 8 (XCDs): 1 600 tiles on 256 CUs are 7
         // rounds whether 256 workgroups walk them (64 of them seven tiles, 192 six) or 232 (seven each, the last round all but full),
         // and on a chip whose clock is set by power the CUs left idle for the whole launch buy the others a higher one - cfg 3's
-        // launches at batch 200 (1 600 / 400 tiles) 1.5-2.9 % faster, whole-round launches unchanged (tuning bit 24 = one per CU: A/B,
+        // launches at batch 200 (1 600 / 400 tiles) 1.5-2.9 % faster, whole-round launches unchanged (tuning bit 27 = one per CU: A/B,
         // profiles/r05_summary.md section 8)
         const int rounds = (nblk + ncu - 1) / ncu;
         const int g = ((nblk + rounds - 1) / rounds + 7) & ~7;
