@@ -699,7 +699,8 @@ __global__ __launch_bounds__(HT, 2) void conv_halo_kernel(const KParams p) {
                     // the next tile's accumulators, initialised INSIDE this straight-line block: at the common tail below the wait-count
                     // pass has to merge every epilogue variant and drains the counter (vmcnt(0): all eight store acknowledgements + the DMA)
                     if constexpr (cfast) {
-                        // in order behind the bias (and embedding) loads: this block's eight row stores, or none (DF); + its statistics atomic
+                        // (the compiler's wait for the bias / embedding loads lands here: behind them this block issued its residual loads,
+                        //  all consumed above, and - not DF - its eight row stores and statistics atomic)
                         cadd_sum(cq, eq, cnext);
                         if constexpr (DF) {
                             pend = has_stats ? 2 : 1;
